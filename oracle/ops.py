@@ -1,0 +1,144 @@
+"""Functional NumPy restatement of the RALEIGH Vectors/Matrix operations.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+
+Every block is a 2-D array of shape (nvec, dim): one vector per ROW, exactly
+the storage convention of the reference (``raleigh/algebra/dense_ndarray.py:52-83``),
+which is bit-identical to a column-major dim x nvec matrix with ld = dim.
+All functions are pure: they return new arrays and never alias their inputs.
+Citations are relative to the reference tree.
+"""
+
+import numpy as np
+
+
+def _cj(a):
+    return a.conj() if np.iscomplexobj(a) else a
+
+
+def gram(x, y):
+    """``x.dot(y)``: G[i, j] = sum_r conj(y[i, r]) * x[j, r], shape (ny, nx).
+
+    Reference: raleigh/algebra/dense_numpy.py:78-82 (NumPy),
+    raleigh/algebra/dense_cblas.py:105-124 (gemm ConjTrans, then conj).
+    """
+    return _cj(y) @ x.T
+
+
+def dots(x, y):
+    """``x.dots(y)``: v[i] = sum_r conj(y[i, r]) * x[i, r].
+
+    Reference: raleigh/algebra/dense_numpy.py:68-76.
+    """
+    return np.einsum('ir,ir->i', _cj(y), x).astype(x.dtype, copy=False)
+
+
+def dots_transp(x, y):
+    """``x.dots(y, transp=True)``: w[r] = sum_i conj(y[i, r]) * x[i, r].
+
+    Reference: raleigh/algebra/dense_numpy.py:55-66.
+    """
+    return np.einsum('ir,ir->r', _cj(y), x).astype(x.dtype, copy=False)
+
+
+def multiply(x, q):
+    """``x.multiply(q, out)``: out[j, :] = sum_i q[i, j] * x[i, :].
+
+    Reference: raleigh/algebra/dense_numpy.py:84-93 (``numpy.dot(q.T, x)``).
+    """
+    return (q.T @ x).astype(x.dtype, copy=False)
+
+
+def add_q(self_, other, s, q):
+    """``self.add(other, s, q)``: self[j, :] += s * sum_i q[i, j] * other[i, :].
+
+    Reference: raleigh/algebra/dense_numpy.py:95-102.
+    """
+    return (self_ + s * (q.T @ other)).astype(self_.dtype, copy=False)
+
+
+def axpy(self_, other, s):
+    """``self.add(other, s)`` with scalar s: self += s * other.
+
+    Reference: raleigh/algebra/dense_numpy.py:98-99.
+    """
+    return (self_ + s * other).astype(self_.dtype, copy=False)
+
+
+def axpy_cols(self_, other, s):
+    """``self.add(other, s)`` with 1-D s: self[i, :] += s[i] * other[i, :].
+
+    Reference: raleigh/algebra/dense_numpy.py:103-105.
+    """
+    s = np.asarray(s)
+    return (self_ + s[:, None] * other).astype(self_.dtype, copy=False)
+
+
+def copy_cols(x_all, ind):
+    """``x.copy(y, ind)``: gathers vectors ``ind`` (absolute indices into all of
+    x's storage, NOT relative to its selection).
+
+    Reference: raleigh/algebra/dense_numpy.py:35-42.
+    """
+    return x_all[np.asarray(ind, dtype=np.int64), :].copy()
+
+
+def scale_cols(x, s, multiply=False):
+    """``x.scale(s, multiply)``: x[i] *= s[i], or x[i] /= s[i] skipping s[i]==0.
+
+    Reference: raleigh/algebra/dense_numpy.py:44-52.
+    """
+    s = np.asarray(s)
+    out = x.copy()
+    if multiply:
+        out *= s[:, None].astype(x.dtype)
+    else:
+        nz = s != 0
+        out[nz] = (out[nz] / s[nz, None]).astype(x.dtype)
+    return out
+
+
+def dense_apply(a, x, transp=False):
+    """``Matrix(a).apply(x, y, transp)``: rows of y are A x_i (or A^H x_i).
+
+    Reference: raleigh/algebra/dense_numpy.py:153-175.  For transp the
+    reference conjugates x, multiplies by a (un-transposed twice) and
+    conjugates y, i.e. y = conj(conj(x) @ a) = x @ conj(a).
+    """
+    if transp:
+        return (x @ _cj(a)).astype(x.dtype, copy=False)
+    return (x @ a.T).astype(x.dtype, copy=False)
+
+
+def orthogonalize(x, other):
+    """``x.orthogonalize(other)``: q = gram(x, other); x -= q^T other; returns
+    (new_x, q).  Reference: raleigh/algebra/dense_numpy.py:117-123.
+    """
+    q = gram(x, other)
+    return (x - q.T @ other).astype(x.dtype, copy=False), q
+
+
+def svd(x):
+    """``x.svd()``: thin SVD x^T = W^T-ish in the reference's row convention:
+    x (m x n) = v @ diag(sigma) @ w with w (m x n) having orthonormal rows;
+    w replaces x and (sigma, conj(v)) is returned.
+
+    Reference: raleigh/algebra/dense_numpy.py:125-128.
+    """
+    v, sigma, w = np.linalg.svd(x, full_matrices=False)
+    return w.astype(x.dtype, copy=False), sigma, _cj(v)
+
+
+def csr_sym_apply(upper_csr, x):
+    """``SparseSymmetricMatrix.apply``: y_i = A x_i with A given by its upper
+    triangle (symmetric for real, Hermitian for complex data).
+
+    Reference: raleigh/algebra/sparse_mkl.py:18-48 stores triu(A) 1-based and
+    calls mkl_?csrmm with matdescra 'SUNF' / 'HUNF'
+    (raleigh/algebra/mkl_wrap.py:211-276), i.e. A = U + U^H - diag(U).
+    """
+    import scipy.sparse as sp
+    u = sp.csr_matrix(upper_csr)
+    d = sp.diags(u.diagonal())
+    full = u + u.conj().T - d
+    return np.ascontiguousarray((full @ x.T).T).astype(x.dtype, copy=False)

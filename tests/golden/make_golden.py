@@ -1,0 +1,313 @@
+"""Generates the golden fixtures in this directory from the REFERENCE itself.
+
+Run ONLY in the build container, where the reference is mounted read-only at
+/root/reference (it never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's NumPy backend (raleigh/algebra/dense_numpy.py), its
+MKL backend when libmkl_rt.so is loadable (raleigh/algebra/dense_cblas.py,
+sparse_mkl.py) and its core solver / interfaces, feeds them the seeded inputs
+of the reference's own test scripts (tests/tests_algebra.py:517-539,
+tests/tests_matrix.py) and stores inputs + outputs as small .npz files.
+Nothing of the reference's source is stored: fixtures are data only.
+
+The only harness-side adaptation: scipy >= 1.14 dropped the ``turbo`` keyword of
+``scipy.linalg.eigh`` that raleigh/core/solver.py:578,822,899,1470 still passes;
+it is stripped here, in this process, without touching the reference files.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+REF = os.environ.get('RALEIGH_REFERENCE', '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+_eigh = sla.eigh
+
+
+def _eigh_no_turbo(*a, **kw):
+    kw.pop('turbo', None)
+    return _eigh(*a, **kw)
+
+
+sla.eigh = _eigh_no_turbo
+
+from raleigh.algebra.dense_numpy import Vectors as NVectors, Matrix as NMatrix  # noqa: E402
+from raleigh.core.solver import (Problem, Solver, Options,  # noqa: E402
+                                 DefaultConvergenceCriteria)
+
+HAVE_MKL = False
+try:
+    from raleigh.algebra import env
+    env.mkl_path = '/opt/conda/lib'
+    from raleigh.algebra.dense_cblas import Vectors as CVectors  # noqa: E402,F401
+    from raleigh.algebra.sparse_mkl import (SparseSymmetricMatrix,  # noqa: E402
+                                            IncompleteLU)
+    HAVE_MKL = True
+except Exception as e:  # pragma: no cover
+    print('MKL backend not loadable: %r' % e)
+
+DTYPES = {'s': np.float32, 'd': np.float64, 'c': np.complex64, 'z': np.complex128}
+
+
+def algebra_inputs(m, n, key):
+    """tests/tests_algebra.py:517-539: seed(1); u, v = randn(m, n); complex
+    case u + 1j v, v - 2j u."""
+    np.random.seed(1)
+    u = np.random.randn(m, n)
+    v = np.random.randn(m, n)
+    dt = DTYPES[key]
+    if key in 'cz':
+        return (u + 1j * v).astype(dt), (v - 2j * u).astype(dt)
+    return u.astype(dt), v.astype(dt)
+
+
+def per_op(m, n, key, V=NVectors):
+    u0, v0 = algebra_inputs(m, n, key)
+    dt = DTYPES[key]
+    out = {'u': u0, 'v': v0}
+    mk = lambda a: V(a.copy())
+    # dots / dot
+    u, v = mk(u0), mk(v0)
+    out['dots'] = u.dots(v)
+    out['dots_transp'] = u.dots(v, transp=True)
+    p = u.dot(v)
+    out['dot'] = p
+    # windowed dot: self = u[1:1+m-2], other = v[2:]
+    u.select(m - 2, 1)
+    v.select(m - 2, 2)
+    out['dot_window'] = u.dot(v)
+    u.select(m)
+    v.select(m)
+    # multiply with C- and F-ordered q (same numbers)
+    np.random.seed(2)
+    q = np.random.randn(m, m)
+    if key in 'cz':
+        q = q + 1j * np.random.randn(m, m)
+    q = q.astype(dt)
+    out['q'] = q
+    w = mk(v0)
+    u.multiply(q, w)
+    out['multiply'] = w.data().copy()
+    w2 = mk(v0)
+    u.multiply(np.asfortranarray(q), w2)
+    out['multiply_F'] = w2.data().copy()
+    # rectangular q: k = m vectors -> 3 outputs
+    w3 = mk(v0)
+    w3.select(3, 1)
+    u.multiply(q[:, :3].copy(), w3)
+    out['multiply_rect'] = w3.data().copy()
+    # add: scalar, vector, q
+    w = mk(v0)
+    w.add(u, -0.75)
+    out['add_scalar'] = w.data().copy()
+    s = (np.arange(m) - 1.5).astype(dt)
+    if key in 'cz':
+        s = (s * (1 - 0.5j)).astype(dt)
+    out['s_vec'] = s
+    w = mk(v0)
+    w.add(u, s)
+    out['add_vector'] = w.data().copy()
+    w = mk(v0)
+    w.add(u, 2.0, q)
+    out['add_q'] = w.data().copy()
+    w = mk(v0)
+    w.add(u, -1.0, np.asfortranarray(q))
+    out['add_q_F'] = w.data().copy()
+    # scale: multiply and safe divide with a zero entry
+    sc = (np.arange(m) % 3).astype(np.float64) * 1.5   # zeros at 0, 3, ...
+    out['scale_s'] = sc
+    w = mk(u0)
+    w.scale(sc, multiply=True)
+    out['scale_mul'] = w.data().copy()
+    w = mk(u0)
+    w.scale(sc)
+    out['scale_div'] = w.data().copy()
+    # copy with the cyclic-shift index of tests_algebra.py:133-137
+    ind = np.roll(np.arange(m), -1)
+    out['ind'] = ind
+    w = mk(v0)
+    u.copy(w, ind)
+    out['copy_ind'] = w.data().copy()
+    # partial gather into a window
+    w = mk(v0)
+    w.select(2, 1)
+    u.copy(w, ind[:2])
+    w.select(m)
+    out['copy_ind_window'] = w.data().copy()
+    # orthogonalize
+    w = mk(v0)
+    qq = w.orthogonalize(u)
+    out['orth'] = w.data().copy()
+    out['orth_q'] = qq.data().copy()
+    # svd: sigma (vectors are unique up to phases; tests check reconstruction)
+    w = mk(u0)
+    sigma, vh = w.svd()
+    out['svd_sigma'] = sigma
+    return out
+
+
+def matrix_apply(key):
+    """Matrix.apply / apply(transp) / A^T A chain on a random (not all-ones)
+    matrix, C- and F-order (tests/tests_matrix.py:19-152)."""
+    dt = DTYPES[key]
+    np.random.seed(3)
+    M, N, k = 37, 23, 4
+    a = np.random.randn(M, N)
+    x = np.random.randn(k, N)
+    z = np.random.randn(k, M)
+    if key in 'cz':
+        a = a + 1j * np.random.randn(M, N)
+        x = x + 1j * np.random.randn(k, N)
+        z = z + 1j * np.random.randn(k, M)
+    a, x, z = a.astype(dt), x.astype(dt), z.astype(dt)
+    out = {'a': a, 'x': x, 'z': z}
+    for tag, arr in (('C', np.ascontiguousarray(a)), ('F', np.asfortranarray(a))):
+        A = NMatrix(arr)
+        vx, vy = NVectors(x.copy()), NVectors(np.zeros((k, M), dtype=dt))
+        A.apply(vx, vy)
+        out['apply_' + tag] = vy.data().copy()
+        vz, vw = NVectors(z.copy()), NVectors(np.zeros((k, N), dtype=dt))
+        A.apply(vz, vw, transp=True)
+        out['apply_t_' + tag] = vw.data().copy()
+        A.apply(vy, vw, transp=True)
+        out['ata_' + tag] = vw.data().copy()
+    return out
+
+
+def lap3d(nx, ny, nz, ax, ay, az):
+    from raleigh.examples.laplace import lap3d as ref_lap3d
+    return ref_lap3d(nx, ny, nz, ax, ay, az)
+
+
+def sparse_apply():
+    out = {}
+    A = lap3d(6, 5, 4, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    np.random.seed(4)
+    x = np.random.randn(3, n)
+    op = SparseSymmetricMatrix(A)
+    y = np.zeros_like(x)
+    op.apply(x, y)
+    out['lap_x'] = x
+    out['lap_y'] = y
+    out['lap_dense'] = A.toarray()
+    x1 = x[:1].copy()
+    y1 = np.zeros_like(x1)
+    op.apply(x1, y1)       # single real vector takes the csrsymv path
+    out['lap_y1'] = y1
+    # complex Hermitian: lap + i * skew first-neighbour perturbation
+    S = sp.diags([np.full(n - 1, 0.3)], [1], shape=(n, n))
+    H = sp.csr_matrix(A.astype(np.complex128) + 1j * S - 1j * S.T)
+    xz = (np.random.randn(3, n) + 1j * np.random.randn(3, n))
+    opz = SparseSymmetricMatrix(H)
+    yz = np.zeros_like(xz)
+    opz.apply(xz, yz)
+    out['herm_dense'] = H.toarray()
+    out['herm_x'] = xz
+    out['herm_y'] = yz
+    return out
+
+
+def solver_known_answers():
+    res = {}
+    # 1. core_solver doctest (raleigh/examples/core_solver.py:65-71)
+    np.random.seed(1)
+    n = 100
+    opt = Options()
+    opt.block_size = -1
+    opt.convergence_criteria = DefaultConvergenceCriteria()
+    opt.convergence_criteria.set_error_tolerance('eigenvector error', 1e-8)
+    opt.verbosity = -1
+    v = NVectors(n, data_type=np.float64)
+    a = np.arange(1, n + 1).astype(np.float64)
+    evp = Problem(v, NMatrix(np.diag(a)))
+    solver = Solver(evp)
+    status = solver.solve(v, opt, which=(6, 0))
+    res['core_diag100'] = {'status': int(status), 'iterations': int(solver.iteration),
+                           'block_size': int(solver.block_size),
+                           'eigenvalues': solver.eigenvalues.tolist()}
+    if HAVE_MKL:
+        from raleigh.interfaces.partial_hevp import partial_hevp
+        A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
+        np.random.seed(1)
+        opt = Options()
+        lmd, x, status = partial_hevp(A, sigma=0, which=6, tol=1e-6, verb=-1, opt=opt)
+        res['hevp_lap30_si6'] = {'status': int(status), 'eigenvalues': lmd.tolist()}
+        np.random.seed(1)
+        T = IncompleteLU(A)
+        T.factorize()
+        opt = Options()
+        lmd, x, status = partial_hevp(A, T=T, which=10, tol=1e-6, verb=-1, opt=opt)
+        r = A @ x - x * lmd
+        res['hevp_lap30_ilu10'] = {'status': int(status), 'eigenvalues': lmd.tolist(),
+                                   'residual_norms': np.linalg.norm(r, axis=0).tolist()}
+        # no preconditioner (the configuration the device path runs natively)
+        A2 = lap3d(12, 11, 10, 1.0, 1.01, 1.02)
+        np.random.seed(1)
+
+        class Ident:
+            def apply(self, x, y):
+                y[:, :] = x
+        opt = Options()
+        opt.max_iter = 500
+        lmd, x, status = partial_hevp(A2, T=Ident(), which=5, tol=1e-8, verb=-1, opt=opt)
+        res['hevp_lap12_id5'] = {'status': int(status), 'eigenvalues': lmd.tolist()}
+    return res
+
+
+def pca_known_answers():
+    from raleigh.examples.pca.generate_matrix import generate
+    from raleigh.interfaces.pca import pca, pca_error
+    np.random.seed(1)
+    A, sigma, u, v = generate(600, 400, 200, pca=True)
+    mean, trans, comps = pca(A, npc=30)
+    em, ef = pca_error(A, mean, trans, comps)
+    sv = np.linalg.norm(trans, axis=0)
+    As = A - A.mean(axis=0, keepdims=True)
+    exact = np.linalg.svd(As.astype(np.float64), compute_uv=False)[:30]
+    return {'pca_600x400_npc30': {'em': float(em), 'ef': float(ef),
+                                  'sigma': sv.astype(np.float64).tolist(),
+                                  'sigma_exact': exact.tolist()}}
+
+
+def main():
+    shapes = [(5, 257), (16, 192)]
+    for key in DTYPES:
+        for (m, n) in shapes:
+            d = per_op(m, n, key)
+            if HAVE_MKL:   # cross-check the MKL backend against the NumPy one
+                c = per_op(m, n, key, V=CVectors)
+                tol = 2e-5 if key in 'sc' else 1e-12
+                for name in d:
+                    if name == 'svd_sigma' or d[name].dtype.kind not in 'fc':
+                        continue
+                    if name == 'orth_q' and key in 'cz':
+                        # the reference's own backends disagree here: dense_cblas.py:250-251
+                        # returns conj of dense_numpy.py:117-123's q; NumPy is the oracle
+                        continue
+                    den = np.linalg.norm(d[name]) or 1.0
+                    err = np.linalg.norm(c[name] - d[name]) / den
+                    assert err < tol, (key, m, n, name, err)
+            np.savez_compressed(os.path.join(HERE, 'ops_%s_%dx%d.npz' % (key, m, n)), **d)
+        np.savez_compressed(os.path.join(HERE, 'matrix_%s.npz' % key), **matrix_apply(key))
+    if HAVE_MKL:
+        np.savez_compressed(os.path.join(HERE, 'sparse.npz'), **sparse_apply())
+    known = solver_known_answers()
+    known.update(pca_known_answers())
+    known['_meta'] = {'numpy': np.__version__, 'have_mkl': HAVE_MKL,
+                      'reference': 'evgueni-ovtchinnikov/raleigh v1.3.5 @ 2024-12-20'}
+    with open(os.path.join(HERE, 'known_answers.json'), 'w') as f:
+        json.dump(known, f, indent=1)
+    print(json.dumps(known, indent=1)[:3000])
+
+
+if __name__ == '__main__':
+    main()
