@@ -1,0 +1,163 @@
+/*
+ * rlhip.h -- C ABI of librlhip.so, the MI355X (gfx950) abstract-vectors backend
+ * for the RALEIGH block-JCG eigensolver.
+ *
+ * This is the drop-in boundary: the entry points a ctypes binding of the
+ * reference would call in place of libcudart / libcublas / libcusolver
+ * (raleigh/algebra/cuda_wrap.py, cublas_wrap.py) and libmkl_rt
+ * (raleigh/algebra/mkl_wrap.py).  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *  - A block of vectors is a column-major n x m matrix in device memory with
+ *    leading dimension ld (in ELEMENTS, ld >= n): vector j starts at
+ *    base + j*ld.  This is the reference's (nvec, dim) C-ordered array
+ *    (dense_ndarray.py:52-83, dense_cublas.py:355-428) with ld = dim; a
+ *    `select(nv, first)` window is the pointer base + first*ld.
+ *  - All sizes are int64_t (the reference passes c_int and overflows at 2^31).
+ *  - dtype: RLH_S float, RLH_D double, RLH_C complex64, RLH_Z complex128
+ *    (interleaved re,im).
+ *  - Small coefficient arrays (q, s, ind) are HOST pointers, borrowed for the
+ *    call only; q is addressed through element strides so C- and F-ordered
+ *    numpy arrays need no copy (dense_cublas.py:283-294).
+ *  - Results that feed host math are written to HOST pointers; such calls
+ *    synchronise the stream before returning.  Device-only calls are
+ *    asynchronous on the library stream (rlh_set_stream).
+ *  - Every function returns 0 on success, non-zero on failure;
+ *    rlh_last_error() gives the message (the reference raises
+ *    RuntimeError('cuda error %d'), dense_cublas.py:779-781).
+ *  - One calling thread per process; one device per process (one process per
+ *    GPU, RCCL reductions are driven by the caller on the same stream).
+ */
+#ifndef RLHIP_H
+#define RLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLH_VERSION 100
+
+enum { RLH_S = 0, RLH_D = 1, RLH_C = 2, RLH_Z = 3 };
+
+/* ---- context (cuda_wrap.py:139-162; cublas_wrap.py Cublas.__init__) ---- */
+int rlh_version(void);
+const char *rlh_last_error(void);
+int rlh_device_count(int *count);
+/* Binds the process to `device`, creates the stream, pinned staging ring and
+ * reduction workspace.  Idempotent for the same device. */
+int rlh_init(int device);
+int rlh_finalize(void);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) so that
+ * RCCL collectives issued by the caller are ordered with the kernels;
+ * NULL restores the library's own stream. */
+int rlh_set_stream(void *hip_stream);
+int rlh_sync(void);                          /* cuda_wrap.py synchronize */
+int rlh_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+
+/* ---- device memory (cuda_wrap.py malloc/free/memset/memcpy/memcpy2D;
+ *      dense_cublas.py:801-811 _Data) ---- */
+int rlh_malloc(void **dptr, int64_t bytes);
+int rlh_free(void *dptr);
+int rlh_memset(void *dptr, int value, int64_t bytes);            /* async */
+int rlh_h2d(void *dptr, const void *hptr, int64_t bytes);        /* sync  */
+int rlh_d2h(void *hptr, const void *dptr, int64_t bytes);        /* sync  */
+int rlh_d2d(void *dst, const void *src, int64_t bytes);          /* async */
+/* rows x width_bytes strided copy, kind: 0 h2d, 1 d2h, 2 d2d
+ * (dense_cublas.py:61-68 append(axis=1); padded-ld upload/download). */
+int rlh_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch,
+               int64_t width_bytes, int64_t rows, int kind);
+
+/* ---- K1: Gram / dot (dense_numpy.py:78-82; dense_cublas.py:245-269) ----
+ * out[i*mx + j] = sum_r conj(Y[r,i]) * X[r,j], i < my, j < mx
+ * (shape (my, mx), C order == `X.dot(Y)` of the reference).
+ * d_out: device buffer of my*mx elements or NULL (internal buffer);
+ * h_out: host buffer or NULL.  With h_out the call synchronises; with d_out
+ * only, it is asynchronous (the caller all-reduces d_out with RCCL, then
+ * rlh_d2h).  X == Y with equal shapes is detected and read once. */
+int rlh_gram(int dtype, int64_t n, int64_t mx, const void *X, int64_t ldx,
+             int64_t my, const void *Y, int64_t ldy, void *d_out, void *h_out);
+
+/* ---- K2: column-wise dots (dense_numpy.py:68-76; dense_cublas.py:233-243)
+ * out[i] = sum_r conj(Y[r,i]) * X[r,i], i < m. */
+int rlh_dots(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx,
+             const void *Y, int64_t ldy, void *d_out, void *h_out);
+
+/* ---- K2t: transposed dots (dense_numpy.py:55-66; dense_cublas.py:175-221)
+ * d_out[r] = sum_i conj(Y[r,i]) * X[r,i], r < n; device output of n elements. */
+int rlh_dots_transp(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx,
+                    const void *Y, int64_t ldy, void *d_out);
+
+/* ---- K3/K4: block update (dense_numpy.py:84-105; dense_cublas.py:271-342)
+ * Out[:,j] = beta*Out[:,j] + alpha * sum_{i<k} q[i,j] * X[:,i], j < m.
+ * q: HOST, element (i,j) at q[i*q_rs + j*q_cs]; alpha: HOST, 2 doubles (re,im);
+ * beta is 0 (multiply) or 1 (add).  Out must not overlap X. */
+int rlh_block_update(int dtype, int64_t n, int64_t k, const void *X, int64_t ldx,
+                     int64_t m, void *Out, int64_t ldo, const void *q,
+                     int64_t q_rs, int64_t q_cs, const double *alpha, int beta);
+
+/* ---- K5: Y += alpha * X on an n x m window (dense_cublas.py:311-316) ---- */
+int rlh_axpy(int dtype, int64_t n, int64_t m, const double *alpha,
+             const void *X, int64_t ldx, void *Y, int64_t ldy);
+/* ---- K6: Y[:,i] += s[i] * X[:,i]; s HOST, vectors' dtype
+ *      (dense_cublas.py:343-350) ---- */
+int rlh_axpy_cols(int dtype, int64_t n, int64_t m, const void *s,
+                  const void *X, int64_t ldx, void *Y, int64_t ldy);
+/* ---- K7: window copy / column gather (dense_cublas.py:133-153)
+ * rlh_copy: Y[:, j] = X[:, j], j < m.
+ * rlh_copy_cols: Y[:, k] = Xall[:, ind[k]], k < m; ind HOST int64, absolute
+ * indices into the storage Xall points at. */
+int rlh_copy(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx,
+             void *Y, int64_t ldy);
+int rlh_copy_cols(int dtype, int64_t n, int64_t m, const int64_t *ind,
+                  const void *Xall, int64_t ldx, void *Y, int64_t ldy);
+/* ---- K8: column scale (dense_numpy.py:44-52; dense_cublas.py:155-172)
+ * s HOST doubles (re,im pairs when the dtype is complex).
+ * mode 1: X[:,i] *= s[i]; mode 0: X[:,i] /= s[i] unless s[i] == 0. */
+int rlh_scale_cols(int dtype, int64_t n, int64_t m, const double *s, int mode,
+                   void *X, int64_t ldx);
+/* in-place complex conjugate (dense_cublas.py:503-511); no-op for real */
+int rlh_conj(int dtype, int64_t n, int64_t m, void *X, int64_t ldx);
+
+/* ---- K13: sparse symmetric/Hermitian operator
+ *      (sparse_mkl.py:16-48; mkl_wrap.py:204-276 mkl_?csrmm 'SUNF'/'HUNF')
+ * The caller passes the FULL matrix (both triangles) as 0-based CSR in host
+ * memory; rows [row0, row0+n_rows) of a matrix with n_cols columns (row-shard
+ * of the operator).  The library converts to a sliced-ELL device layout.
+ * Y[:, j] = A * X[:, j]; X has n_cols rows, Y has n_rows rows. */
+typedef struct rlh_csr *rlh_csr_t;
+int rlh_csr_create(rlh_csr_t *h, int dtype, int64_t n_rows, int64_t n_cols,
+                   const int64_t *indptr, const int32_t *indices,
+                   const void *values);
+int rlh_csr_destroy(rlh_csr_t h);
+int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
+                 int64_t *device_bytes);
+/* Columns [0, n_own) are read from X, columns [n_own, n_cols) from the halo block
+ * H (row c - n_own), which holds the off-shard rows received from other ranks;
+ * single GPU: n_own = n_cols, H = NULL. */
+int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own,
+             const void *H, int64_t ldh, void *Y, int64_t ldy);
+/* Packs rows for the halo exchange: Out[i, j] = X[idx[i], j], i < nidx, j < m;
+ * idx: DEVICE int64 (built once per operator). */
+int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m,
+                    const void *X, int64_t ldx, void *Out, int64_t ldo);
+
+/* ---- K12: dense operator (dense_numpy.py:153-175; dense_cublas.py:732-776)
+ * A: DEVICE, M x N, row-major (order 0, numpy C_CONTIGUOUS, lda >= N) or
+ * column-major (order 1, F_CONTIGUOUS, lda >= M).
+ * transp 0: Y[:, j] = A   * X[:, j]   (X: N rows, Y: M rows)
+ * transp 1: Y[:, j] = A^H * X[:, j]   (X: M rows, Y: N rows) */
+int rlh_dense_apply(int dtype, int64_t M, int64_t N, const void *A, int64_t lda,
+                    int order, int transp, int64_t m, const void *X,
+                    int64_t ldx, void *Y, int64_t ldy);
+
+/* ---- profiling aid: HIP-event time of the last `count` kernels ---- */
+int rlh_timer_start(void);
+int rlh_timer_stop(float *milliseconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLHIP_H */

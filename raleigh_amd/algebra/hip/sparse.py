@@ -1,0 +1,112 @@
+"""MI355X sparse symmetric/Hermitian operator for SciPy sparse matrices.
+
+Counterpart of raleigh/algebra/sparse_mkl.py:16-48 (SparseSymmetricMatrix) and
+:143-154 (Operator): same constructor argument (a SciPy sparse matrix whose
+UPPER triangle defines the symmetric/Hermitian operator, as MKL's 'SUNF'/'HUNF'
+descriptor does), same ``apply(x, y)``, but x and y are device Vectors and the
+product runs in librlhip.so (rlh_spmm) on a sliced-ELL copy of the full matrix.
+"""
+
+import ctypes
+
+import numpy as np
+import scipy.sparse as scs
+
+from ... import _lib
+
+
+def full_from_upper(matrix):
+    """A = U + U^H - diag(U) from U = triu(matrix): what the reference's MKL call
+    computes with (raleigh/algebra/mkl_wrap.py:211-276)."""
+    u = scs.triu(matrix, format='csr')
+    s = scs.triu(matrix, k=1, format='csr')
+    full = scs.csr_matrix(u + s.conj().T)
+    full.sort_indices()
+    return full
+
+
+class CsrOperator:
+    """Device CSR (sliced-ELL) operator: y = A x for rows owned by this process."""
+
+    def __init__(self, csr, n_own=None):
+        csr = scs.csr_matrix(csr)
+        csr.sort_indices()
+        dt = csr.data.dtype.type
+        if dt not in _lib.DTYPE_CODE:
+            raise ValueError('unsupported data type')
+        self._dtype = dt
+        self._shape = csr.shape
+        self._nnz = int(csr.nnz)
+        self._n_own = csr.shape[1] if n_own is None else int(n_own)
+        indptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        values = np.ascontiguousarray(csr.data)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().rlh_csr_create(ctypes.byref(h), _lib.DTYPE_CODE[dt], csr.shape[0],
+                                             csr.shape[1], _lib.host_ptr(indptr),
+                                             _lib.host_ptr(indices), _lib.host_ptr(values)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.library().rlh_csr_destroy(h)
+            except Exception:
+                pass
+
+    def shape(self):
+        return self._shape
+
+    def nnz(self):
+        return self._nnz
+
+    def data_type(self):
+        return self._dtype
+
+    def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0):
+        _lib.check(_lib.lib().rlh_spmm(self._h, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
+
+
+class SparseSymmetricMatrix:
+
+    def __init__(self, matrix):
+        try:
+            upper = matrix.csr()
+        except Exception:
+            upper = scs.triu(matrix, format='csr')
+            upper.sort_indices()
+        self.__csr = upper
+        self.__op = CsrOperator(full_from_upper(upper))
+
+    def size(self):
+        return self.__csr.shape[0]
+
+    def data_type(self):
+        return self.__csr.data.dtype
+
+    def csr(self):
+        return self.__csr
+
+    def nnz_full(self):
+        return self.__op.nnz()
+
+    def apply(self, x, y):
+        if x.data_type() != self.__op.data_type() or y.data_type() != self.__op.data_type():
+            raise ValueError('Matrix and vectors data types differ')
+        if x.dimension() != self.size() or y.dimension() != self.size():
+            raise ValueError('Matrix and vectors dimensions incompatible')
+        if x.nvec() != y.nvec():
+            raise ValueError('Numbers of input and output vectors differ')
+        self.__op.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
+
+
+class Operator:
+    """Wraps a user operator with ``apply(x, y)`` acting on device Vectors
+    (raleigh/algebra/sparse_mkl.py:143-154 passes host arrays instead)."""
+
+    def __init__(self, op):
+        self.__op = op
+
+    def apply(self, x, y):
+        self.__op.apply(x, y)

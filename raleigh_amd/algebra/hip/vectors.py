@@ -1,0 +1,380 @@
+"""MI355X implementation of RALEIGH's abstract Vectors type.
+
+Same method surface, argument meaning and error behaviour as the reference
+backends (contract: raleigh/core/solver.py:22-96; semantic oracle:
+raleigh/algebra/dense_numpy.py; the backend this one stands in for:
+raleigh/algebra/dense_cublas.py), so ``raleigh/core/solver.py`` can drive it
+unchanged.  All arithmetic runs in librlhip.so (include/rlhip.h); this file is
+bookkeeping: storage, selection windows, host<->device conventions.
+
+Storage: one device allocation holding `capacity` vectors of `ld >= dim`
+elements each (column-major dim x capacity, the reference's (nvec, dim)
+C-ordered array); ld is padded to a multiple of 32 elements so every vector
+starts 128-byte aligned and the kernels take their 16-byte vector-load paths.
+"""
+
+import numbers
+
+import numpy as np
+
+from ... import _lib
+from .memory import DeviceBuffer, upload, download
+
+_LD_ALIGN = 32          # elements
+_MIN_INC, _MAX_INC = 16, 1024     # append() growth (dense_cublas.py:424-425)
+
+
+def _padded(n):
+    return max(_LD_ALIGN, (int(n) + _LD_ALIGN - 1) // _LD_ALIGN * _LD_ALIGN)
+
+
+class Vectors:
+    '''HIP/CDNA4 implementation of the Vectors type.'''
+
+    # ------------------------------------------------------------ construction
+    def __init__(self, arg, nvec=0, data_type=None, shallow=False):
+        self._off = 0          # element offset of vector 0 inside the buffer
+        if isinstance(arg, Vectors):
+            f, k = arg.selected()
+            self._set_type(arg.data_type())
+            self._vdim, self._ld = arg._vdim, arg._ld
+            if shallow:          # a view of the selected window (dense_ndarray.py:55-56)
+                self._buf = arg._buf
+                self._off = arg._off + f * arg._ld
+            else:
+                self._buf = DeviceBuffer(max(k, 1) * self._ld * self._es, zero=False)
+                if k > 0:
+                    _lib.check(_lib.lib().rlh_copy(self._code, self._vdim, k, arg._ptr(), arg._ld,
+                                                   self._buf.ptr, self._ld))
+            nv = k
+        elif _is_matrix(arg):
+            if arg.order() != 'C_CONTIGUOUS':
+                raise ValueError('Vectors data must be C_CONTIGUOUS')
+            nv, n = arg.shape()
+            self._set_type(arg.data_type())
+            self._vdim, self._ld = n, arg.lda()
+            if shallow:
+                self._buf = arg.matrix_data()
+            else:
+                self._buf = DeviceBuffer(max(nv, 1) * self._ld * self._es, zero=False)
+                _lib.check(_lib.lib().rlh_d2d(self._buf.ptr, arg.data_ptr(), nv * self._ld * self._es))
+        elif isinstance(arg, np.ndarray):
+            if arg.ndim != 2:
+                raise ValueError('Vectors data must be a 2D array')
+            nv, n = arg.shape
+            self._set_type(arg.dtype.type)
+            self._vdim, self._ld = n, _padded(n)
+            self._buf = DeviceBuffer(max(nv, 1) * self._ld * self._es)
+            upload(self._buf.ptr, self._ld * self._es, np.ascontiguousarray(arg))
+        elif isinstance(arg, numbers.Number):
+            self._set_type(np.float64 if data_type is None else data_type)
+            n, nv = int(arg), int(nvec)
+            assert nv >= 0
+            self._vdim, self._ld = n, _padded(n)
+            self._buf = DeviceBuffer(nv * self._ld * self._es) if nv > 0 else None
+        else:
+            raise ValueError('wrong argument %s in constructor' % repr(type(arg)))
+        self._nvec = nv
+        self._mvec = nv
+        self._sel = (0, nv)
+        self._inc = _MIN_INC
+
+    def _set_type(self, dt):
+        dt = np.dtype(dt).type
+        if dt not in _lib.DTYPE_CODE:
+            raise ValueError('data type %s not supported' % repr(dt))
+        self._dtype = dt
+        self._code = _lib.DTYPE_CODE[dt]
+        self._es = _lib.DTYPE_SIZE[dt]
+        self._is_complex = dt in (np.complex64, np.complex128)
+
+    # ------------------------------------------------------------ device addressing
+    def _ptr(self, first=None):
+        """Device address of the first selected vector (or of vector `first`)."""
+        f = self._sel[0] if first is None else first
+        base = self._buf.ptr if self._buf is not None else 0
+        return base + (self._off + f * self._ld) * self._es
+
+    def data_ptr(self):
+        return self._ptr()
+
+    def all_data_ptr(self):
+        return self._ptr(0)
+
+    def ld(self):
+        return self._ld
+
+    def data_size(self):
+        return self._es
+
+    def vectors_data(self):
+        return self._buf
+
+    # ------------------------------------------------------------ solver-facing methods
+    def new_vectors(self, arg=0, dim=None):
+        if isinstance(arg, numbers.Number):
+            return Vectors(self.dimension() if dim is None else dim, int(arg), self.data_type())
+        return Vectors(arg)
+
+    def dimension(self):
+        return self._vdim
+
+    def select(self, nv, first=0):
+        assert nv <= self._nvec and first >= 0
+        self._sel = (int(first), int(nv))
+
+    def selected(self):
+        return self._sel
+
+    def clone(self):
+        return Vectors(self)
+
+    def append(self, other, axis=0):
+        if other.nvec() < 1:
+            return
+        L = _lib.lib()
+        if axis == 1:          # lengthen every vector (dense_cublas.py:44-72)
+            m, n = self.shape()
+            l, n_other = other.shape()
+            if m != l:
+                raise ValueError('Cannot append %d vectors to %d vectors' % (l, m))
+            if self.data_type() != other.data_type():
+                raise ValueError('Cannot append %s vectors to %s vectors'
+                                 % (repr(other.data_type()), repr(self.data_type())))
+            n_new = n + n_other
+            ld_new = _padded(n_new)
+            buf = DeviceBuffer(max(m, 1) * ld_new * self._es)
+            es = self._es
+            _lib.check(L.rlh_copy2d(buf.ptr, ld_new * es, self._ptr(0), self._ld * es, n * es, m, 2))
+            _lib.check(L.rlh_copy2d(buf.ptr + n * es, ld_new * es, other._ptr(0), other._ld * es,
+                                    n_other * es, m, 2))
+            self._buf, self._off, self._ld, self._vdim, self._mvec = buf, 0, ld_new, n_new, m
+            return
+        if self.data_type() != other.data_type() or self.dimension() != other.dimension():
+            raise ValueError('Cannot append vectors of different type or dimension')
+        i, m = self.selected()
+        j, l = other.selected()
+        nvec = i + m + l
+        if nvec > self._mvec or self._buf is None or self._off != 0:
+            mvec = ((nvec - 1) // self._inc + 1) * self._inc
+            buf = DeviceBuffer(mvec * self._ld * self._es, zero=False)
+            if i + m > 0:
+                _lib.check(L.rlh_copy(self._code, self._vdim, i + m, self._ptr(0), self._ld,
+                                      buf.ptr, self._ld))
+            self._buf, self._off, self._mvec = buf, 0, mvec
+            if self._inc < _MAX_INC:
+                self._inc *= 2
+        _lib.check(L.rlh_copy(self._code, self._vdim, l, other._ptr(), other._ld,
+                              self._ptr(i + m), self._ld))
+        self._nvec = nvec
+        self.select_all()
+
+    def nvec(self):
+        return self._sel[1]
+
+    def data_type(self):
+        return self._dtype
+
+    def fill_random(self):
+        # host RNG then H2D, as the reference does (dense_cublas.py:119-131), so that
+        # numpy.random.seed(...) gives the same start vectors on every backend
+        m, n = self.nvec(), self.dimension()
+        if m < 1:
+            return
+        data = np.random.rand(m, n).astype(self.data_type())
+        data *= 2
+        data -= 1
+        upload(self._ptr(), self._ld * self._es, data)
+
+    def copy(self, other, ind=None):
+        L = _lib.lib()
+        i, m = self.selected()
+        j, l = other.selected()
+        if ind is None:
+            assert m == l
+            _lib.check(L.rlh_copy(self._code, self._vdim, m, self._ptr(), self._ld,
+                                  other._ptr(), other._ld))
+        else:
+            idx = np.ascontiguousarray(ind, dtype=np.int64)
+            if idx.size and (idx.min() < 0 or idx.max() >= self._nvec):
+                raise IndexError('vector index out of range in copy()')
+            _lib.check(L.rlh_copy_cols(self._code, self._vdim, idx.size, _lib.host_ptr(idx),
+                                       self._ptr(0), self._ld, other._ptr(), other._ld))
+
+    def scale(self, s, multiply=False):
+        m = self.nvec()
+        if m < 1:
+            return
+        s = np.asarray(s)[:m]
+        if self._is_complex:
+            sd = np.ascontiguousarray(s.astype(np.complex128)).view(np.float64)
+        else:
+            sd = np.ascontiguousarray(s.real if np.iscomplexobj(s) else s, dtype=np.float64)
+        _lib.check(_lib.lib().rlh_scale_cols(self._code, self._vdim, m, _lib.host_ptr(sd),
+                                             1 if multiply else 0, self._ptr(), self._ld))
+
+    def dots(self, other, transp=False):
+        L = _lib.lib()
+        m, n = self.nvec(), self.dimension()
+        if transp:
+            w = np.zeros((n,), dtype=self.data_type())
+            if n > 0:
+                tmp = DeviceBuffer(n * self._es, zero=False)
+                _lib.check(L.rlh_dots_transp(self._code, n, m, self._ptr(), self._ld,
+                                             other._ptr(), other._ld, tmp.ptr))
+                _lib.check(L.rlh_d2h(_lib.host_ptr(w), tmp.ptr, n * self._es))
+            return w
+        v = np.zeros((m,), dtype=self.data_type())
+        if m > 0:
+            _lib.check(L.rlh_dots(self._code, n, m, self._ptr(), self._ld, other._ptr(), other._ld,
+                                  None, _lib.host_ptr(v)))
+        return v
+
+    def dot(self, other):
+        m, k = self.nvec(), other.nvec()
+        q = np.zeros((k, m), dtype=self.data_type())
+        if m > 0 and k > 0:
+            _lib.check(_lib.lib().rlh_gram(self._code, self.dimension(), m, self._ptr(), self._ld,
+                                           k, other._ptr(), other._ld, None, _lib.host_ptr(q)))
+        return q
+
+    def _update(self, q, src, dst, alpha, beta):
+        q = np.asarray(q)
+        if q.dtype.type != self._dtype:
+            q = q.astype(self._dtype)
+        if q.ndim != 2 or any(st < 0 for st in q.strides) or any(st % q.itemsize for st in q.strides):
+            q = np.ascontiguousarray(q)
+        k, m = q.shape
+        if k != src.nvec() or m != dst.nvec():
+            raise ValueError('coefficient matrix shape %s does not match %d -> %d vectors'
+                             % (repr(q.shape), src.nvec(), dst.nvec()))
+        a = np.array([np.real(alpha), np.imag(alpha)], dtype=np.float64)
+        _lib.check(_lib.lib().rlh_block_update(
+            self._code, self._vdim, k, src._ptr(), src._ld, m, dst._ptr(), dst._ld,
+            _lib.host_ptr(q), q.strides[0] // q.itemsize, q.strides[1] // q.itemsize,
+            _lib.host_ptr(a), beta))
+
+    def multiply(self, q, output):
+        assert output.nvec() == q.shape[1]
+        self._update(q, self, output, 1.0, 0)
+
+    def add(self, other, s, q=None):
+        L = _lib.lib()
+        m = other.nvec()
+        if np.isscalar(s):
+            if q is None:
+                a = np.array([np.real(s), np.imag(s)], dtype=np.float64)
+                _lib.check(L.rlh_axpy(self._code, self._vdim, m, _lib.host_ptr(a),
+                                      other._ptr(), other._ld, self._ptr(), self._ld))
+            else:
+                self._update(q, other, self, s, 1)
+        else:
+            sv = np.ascontiguousarray(np.asarray(s)[:m], dtype=self._dtype)
+            _lib.check(L.rlh_axpy_cols(self._code, self._vdim, m, _lib.host_ptr(sv),
+                                       other._ptr(), other._ld, self._ptr(), self._ld))
+
+    # ------------------------------------------------------------ other methods of the reference backends
+    def shape(self):
+        return (self._nvec, self._vdim)
+
+    def first(self):
+        return self._sel[0]
+
+    def select_all(self):
+        self.select(self._nvec)
+
+    def reference(self):
+        return Vectors(self, shallow=True)
+
+    def is_complex(self):
+        return self._is_complex
+
+    def conjugate(self):
+        if self._is_complex and self.nvec() > 0:
+            _lib.check(_lib.lib().rlh_conj(self._code, self._vdim, self.nvec(), self._ptr(), self._ld))
+
+    def zero(self):
+        m = self.nvec()
+        if m < 1:
+            return
+        L = _lib.lib()
+        if self._ld == self._vdim:
+            _lib.check(L.rlh_memset(self._ptr(), 0, m * self._ld * self._es))
+        else:
+            for i in range(m):
+                _lib.check(L.rlh_memset(self._ptr(self._sel[0] + i), 0, self._vdim * self._es))
+
+    def fill(self, data):
+        if not isinstance(data, np.ndarray):        # fill(value), as dense_ndarray.py:98-100
+            data = np.full((self.nvec(), self._vdim), data, dtype=self._dtype)
+        m, n = data.shape
+        if m != self.nvec() or n != self._vdim:
+            raise ValueError('mismatching dimensions in fill()')
+        if m < 1:
+            return
+        if data.dtype.type != self._dtype:
+            raise ValueError('mismatching data types in fill()')
+        upload(self._ptr(), self._ld * self._es, np.ascontiguousarray(data))
+
+    def data(self, i=None):
+        """Host COPY of the selected vectors, shape (nvec, dim) (dense_cublas.py:620-629)."""
+        m, n = self.nvec(), self.dimension()
+        if i is not None:
+            v = np.ndarray((1, n), dtype=self._dtype)
+            download(v, self._ptr(self._sel[0] + i), self._ld * self._es)
+            return v[0]
+        v = np.ndarray((m, n), dtype=self._dtype)
+        if m > 0:
+            download(v, self._ptr(), self._ld * self._es)
+        return v
+
+    def asarray(self):
+        return self.data().T
+
+    def orthogonalize(self, other):
+        # q = <self, other>; self -= other * q (dense_numpy.py:117-123)
+        q = self.dot(other)
+        self.add(other, -1.0, q)
+        return self.new_vectors(q)
+
+    def svd(self):
+        """Thin SVD in place: self (as an n x m matrix) = W diag(sigma) V^T with W
+        orthonormal replacing self; returns (sigma, conj(V)) like
+        dense_numpy.py:125-128 / dense_cublas.py:537-591 (gesvd 'O').
+
+        Device algorithm: two passes of scaled Gram + host eigh + block update
+        (the second pass removes the squared-condition loss of the first),
+        then a small host SVD of the accumulated m x m factor."""
+        import scipy.linalg as sla
+        m = self.nvec()
+        real_dt = np.float32 if self._dtype in (np.float32, np.complex64) else np.float64
+        if m < 1:
+            return np.zeros((0,), dtype=real_dt), np.zeros((0, 0), dtype=self._dtype)
+        w = self.new_vectors(m)
+        T = np.eye(m, dtype=np.complex128 if self._is_complex else np.float64)
+        src, dst = self, w
+        for _ in range(2):
+            G = src.dot(src).astype(T.dtype)
+            d = np.sqrt(np.abs(np.real(np.diag(G))))
+            d[d == 0] = 1.0
+            Gs = (G / d[:, None]) / d[None, :]
+            lam, P = sla.eigh((Gs + Gs.conj().T) / 2)
+            lam = np.maximum(lam, np.finfo(real_dt).eps * max(lam[-1], 0.0) + np.finfo(np.float64).tiny)
+            # G[i,j] = <x_i, x_j> = (X^H X)[i,j]  =>  X (D^-1 P lam^-1/2) has orthonormal columns
+            Ti = (P / np.sqrt(lam)[None, :]) / d[:, None]
+            src.multiply(Ti.astype(self._dtype), dst)
+            T = T @ Ti
+            src, dst = dst, src
+        # self_original = src * R with R = T^-1 ; R = Ur S Vr^H
+        R = np.linalg.inv(T)
+        Ur, S, Vrh = np.linalg.svd(R)
+        src.multiply(Ur.astype(self._dtype), dst)
+        if dst is not self:
+            dst.copy(self)
+        # X = W S Vr^H = W S v^T  =>  v = conj(Vr); the reference returns conj(v) = Vr
+        return S.astype(real_dt), Vrh.conj().T.astype(self._dtype)
+
+
+def _is_matrix(arg):
+    from .matrix import Matrix
+    return isinstance(arg, Matrix)

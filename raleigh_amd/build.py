@@ -1,0 +1,63 @@
+"""Builds librlhip.so (gfx950) in-tree with hipcc.
+
+``python -m raleigh_amd.build`` or ``raleigh_amd.build.build_library()``.
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but
+travels with the tree to the GPU box.
+"""
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+LIBDIR = os.path.join(PKG, 'lib')
+LIBPATH = os.path.join(LIBDIR, 'librlhip.so')
+SOURCES = ['context', 'gram', 'update', 'spmm', 'dense']
+FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result']
+
+
+def _newest_source_mtime():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    files.append(os.path.join(ROOT, 'include', 'rlhip.h'))
+    return max(os.path.getmtime(f) for f in files)
+
+
+def is_up_to_date():
+    return os.path.exists(LIBPATH) and os.path.getmtime(LIBPATH) >= _newest_source_mtime()
+
+
+def build_library(force=False, verbose=False):
+    """Compiles every csrc/*.hip for gfx950 and links lib/librlhip.so."""
+    if not force and is_up_to_date():
+        return LIBPATH
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    inc = ['-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+
+    def compile_one(name):
+        src = os.path.join(CSRC, name + '.hip')
+        obj = os.path.join(objdir, name + '.o')
+        cmd = [hipcc] + FLAGS + inc + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])
+    return LIBPATH
+
+
+if __name__ == '__main__':
+    print(build_library(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,295 @@
+// K12: dense operator Y = A X / Y = A^H X on a block of vectors (the PCA A^T A path).
+//
+// Reference: one gemm(Trans|NoTrans|ConjTrans, NoTrans, ny, k, nx, 1, A, lda, x, nx, 0, y, ny)
+// per application (raleigh/algebra/dense_cublas.py:732-776; dense_numpy.py:153-175); complex
+// transp on C-ordered A conjugates x and y around the call (dense_cublas.py:750-776).
+//
+// fp32: LDS-tiled GEMM on v_mfma_f32_32x32x2_f32.  C^T tile of (BN vectors) x (64 output rows)
+// per 256-thread workgroup, BK = 32, register-prefetched next tile, LDS rows padded to 33
+// floats so the per-lane fragment reads (32 rows x 1 k) are bank-conflict free.  The vector
+// index rides the MFMA row and the output-row index rides the MFMA column (= lane & 31), so
+// each accumulator register stores as 128-byte contiguous runs of the column-major Y.
+// Other dtypes (f64, complex): generic LDS-tiled VALU kernel (parity path; the BASELINE dense
+// configurations are fp32).
+#include "common.h"
+
+namespace rlh {
+
+struct DenseArgs {
+  const void *A; int64_t lda;
+  int a_kcontig;        // 1: Op(i,k) = A[i*lda + k]; 0: Op(i,k) = A[k*lda + i]
+  int conj_a;           // complex only
+  int64_t ny, nx;       // Op is ny x nx
+  const void *X; int64_t ldx;
+  void *Y; int64_t ldy;
+  int m;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BN>
+__global__ __launch_bounds__(256) void dense_mfma_f32_kernel(DenseArgs a) {
+  constexpr int BM = 64, BK = 32, SK = BK + 1;
+  constexpr int WGN = (BN >= 64) ? 2 : 1;          // waves along the vector dimension
+  constexpr int WGM = 4 / WGN;                     // waves along the output-row dimension
+  constexpr int TN = BN / WGN / 32;                // 32x32 tiles per wave (vectors)
+  constexpr int TM = BM / WGM / 32 > 0 ? BM / WGM / 32 : 1;
+  static_assert(BM / WGM >= 32 || WGM == 4, "tile split");
+  constexpr int MROWS = (WGM == 4) ? 128 : BM;     // BN == 32 uses a 128-row tile so 4 waves stay busy
+  constexpr int A_UNITS = MROWS * BK / 4 / 256;    // 16-byte units per thread
+  constexpr int B_UNITS = BN * BK / 4 / 256 > 0 ? BN * BK / 4 / 256 : 1;
+
+  __shared__ float ldsA[MROWS * SK];
+  __shared__ float ldsB[BN * SK];
+
+  const float *A = (const float *)a.A;
+  const float *X = (const float *)a.X;
+  float *Y = (float *)a.Y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int64_t i0 = (int64_t)blockIdx.x * MROWS;
+  const int v0 = blockIdx.y * BN;
+
+  float4 ra[A_UNITS], rb[B_UNITS];
+
+  auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+    for (int q = 0; q < A_UNITS; ++q) {
+      const int u = tid + q * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.a_kcontig) {           // unit = 4 consecutive k of one output row
+        const int r = u / (BK / 4), kq = (u % (BK / 4)) * 4;
+        const int64_t i = i0 + r, k = k0 + kq;
+        if (i < a.ny) {
+          const float *p = A + i * a.lda + k;
+          if (k + 3 < a.nx && ((((uintptr_t)p) & 15) == 0)) v = *(const float4 *)p;
+          else {
+            if (k + 0 < a.nx) v.x = p[0];
+            if (k + 1 < a.nx) v.y = p[1];
+            if (k + 2 < a.nx) v.z = p[2];
+            if (k + 3 < a.nx) v.w = p[3];
+          }
+        }
+      } else {                     // unit = 4 consecutive output rows at one k
+        const int kk = u / (MROWS / 4), rq = (u % (MROWS / 4)) * 4;
+        const int64_t i = i0 + rq, k = k0 + kk;
+        if (k < a.nx) {
+          const float *p = A + k * a.lda + i;
+          if (i + 3 < a.ny && ((((uintptr_t)p) & 15) == 0)) v = *(const float4 *)p;
+          else {
+            if (i + 0 < a.ny) v.x = p[0];
+            if (i + 1 < a.ny) v.y = p[1];
+            if (i + 2 < a.ny) v.z = p[2];
+            if (i + 3 < a.ny) v.w = p[3];
+          }
+        }
+      }
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < B_UNITS; ++q) {
+      const int u = tid + q * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = u / (BK / 4), kq = (u % (BK / 4)) * 4;
+      const int64_t k = k0 + kq;
+      if (u < BN * BK / 4 && v0 + c < a.m) {
+        const float *p = X + (int64_t)(v0 + c) * a.ldx + k;
+        if (k + 3 < a.nx && ((((uintptr_t)p) & 15) == 0)) v = *(const float4 *)p;
+        else {
+          if (k + 0 < a.nx) v.x = p[0];
+          if (k + 1 < a.nx) v.y = p[1];
+          if (k + 2 < a.nx) v.z = p[2];
+          if (k + 3 < a.nx) v.w = p[3];
+        }
+      }
+      rb[q] = v;
+    }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int q = 0; q < A_UNITS; ++q) {
+      const int u = tid + q * 256;
+      if (a.a_kcontig) {
+        const int r = u / (BK / 4), kq = (u % (BK / 4)) * 4;
+        float *d = ldsA + r * SK + kq;
+        d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
+      } else {
+        const int kk = u / (MROWS / 4), rq = (u % (MROWS / 4)) * 4;
+        float *d = ldsA + rq * SK + kk;
+        d[0] = ra[q].x; d[SK] = ra[q].y; d[2 * SK] = ra[q].z; d[3 * SK] = ra[q].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < B_UNITS; ++q) {
+      const int u = tid + q * 256;
+      if (u < BN * BK / 4) {
+        const int c = u / (BK / 4), kq = (u % (BK / 4)) * 4;
+        float *d = ldsB + c * SK + kq;
+        d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w;
+      }
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
+
+  const int fr = lane & 31, fk = lane >> 5;
+  const int mrow0 = wm * (MROWS / WGM), vcol0 = wn * (BN / WGN);
+  load_tiles(0);
+  for (int64_t k0 = 0; k0 < a.nx; k0 += BK) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < a.nx) load_tiles(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float fx[TN], fa[TM];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fx[tn] = ldsB[(vcol0 + tn * 32 + fr) * SK + 2 * ks + fk];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[tm] = ldsA[(mrow0 + tm * 32 + fr) * SK + 2 * ks + fk];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fx[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+    }
+  }
+  // D[v][i]: col (lane & 31) = output row i, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = vector v
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int v = v0 + vcol0 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t i = i0 + mrow0 + tm * 32 + (lane & 31);
+        if (v < a.m && i < a.ny) Y[i + (int64_t)v * a.ldy] = acc[tn][tm][r];
+      }
+}
+
+// Generic VALU GEMM for f64 / complex: 64 x 64 output tile, BK = 16, 4 x 4 micro-tile per thread.
+template <typename T, bool CONJ>
+__global__ __launch_bounds__(256) void dense_valu_kernel(DenseArgs a) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  __shared__ T ldsA[BK][BM + 1];
+  __shared__ T ldsB[BK][BN + 1];
+  const T *A = (const T *)a.A;
+  const T *X = (const T *)a.X;
+  T *Y = (T *)a.Y;
+  const int tid = threadIdx.x;
+  const int ti = tid % 16, tv = tid / 16;          // micro-tile: rows ti*4.., vectors tv*4..
+  const int64_t i0 = (int64_t)blockIdx.x * BM;
+  const int v0 = blockIdx.y * BN;
+  T acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = zero_of(T{});
+  for (int64_t k0 = 0; k0 < a.nx; k0 += BK) {
+    for (int u = tid; u < BM * BK; u += 256) {
+      int r, kk;
+      if (a.a_kcontig) { r = u / BK; kk = u % BK; } else { kk = u / BM; r = u % BM; }
+      const int64_t i = i0 + r, k = k0 + kk;
+      T v = zero_of(T{});
+      if (i < a.ny && k < a.nx) v = a.a_kcontig ? A[i * a.lda + k] : A[k * a.lda + i];
+      ldsA[kk][r] = v;
+    }
+    for (int u = tid; u < BN * BK; u += 256) {
+      const int c = u / BK, kk = u % BK;
+      const int64_t k = k0 + kk;
+      T v = zero_of(T{});
+      if (v0 + c < a.m && k < a.nx) v = X[(int64_t)(v0 + c) * a.ldx + k];
+      ldsB[kk][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      T fa[4], fx[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) fa[p] = ldsA[kk][ti * 4 + p];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fx[q] = ldsB[kk][tv * 4 + q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (CONJ) fma_conj_acc(acc[p][q], fa[p], fx[q]);
+          else fma_acc(acc[p][q], fa[p], fx[q]);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t i = i0 + ti * 4 + p;
+      const int v = v0 + tv * 4 + q;
+      if (i < a.ny && v < a.m) Y[i + (int64_t)v * a.ldy] = acc[p][q];
+    }
+}
+
+template <int DT>
+static int dense_impl(const DenseArgs &a) {
+  using T = typename DType<DT>::T;
+  Context &c = ctx();
+  if constexpr (DT == RLH_S) {
+    if (a.m > 64) {
+      dim3 grid((unsigned)((a.ny + 63) / 64), (unsigned)((a.m + 127) / 128));
+      hipLaunchKernelGGL((dense_mfma_f32_kernel<128>), grid, dim3(256), 0, c.stream, a);
+    } else if (a.m > 32) {
+      dim3 grid((unsigned)((a.ny + 63) / 64), 1);
+      hipLaunchKernelGGL((dense_mfma_f32_kernel<64>), grid, dim3(256), 0, c.stream, a);
+    } else {
+      dim3 grid((unsigned)((a.ny + 127) / 128), 1);
+      hipLaunchKernelGGL((dense_mfma_f32_kernel<32>), grid, dim3(256), 0, c.stream, a);
+    }
+  } else {
+    dim3 grid((unsigned)((a.ny + 63) / 64), (unsigned)((a.m + 63) / 64));
+    if (a.conj_a)
+      hipLaunchKernelGGL((dense_valu_kernel<T, true>), grid, dim3(256), 0, c.stream, a);
+    else
+      hipLaunchKernelGGL((dense_valu_kernel<T, false>), grid, dim3(256), 0, c.stream, a);
+  }
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rlh
+
+using namespace rlh;
+
+extern "C" int rlh_dense_apply(int dtype, int64_t M, int64_t N, const void *A, int64_t lda, int order, int transp,
+                               int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_dense_apply: unknown dtype %d", dtype);
+  RLH_REQUIRE(M >= 0 && N >= 0 && m >= 0, "rlh_dense_apply: negative size");
+  RLH_REQUIRE(order == 0 || order == 1, "rlh_dense_apply: order must be 0 (row-major) or 1 (column-major)");
+  RLH_REQUIRE(transp == 0 || transp == 1, "rlh_dense_apply: transp must be 0 or 1");
+  const int64_t ny = transp ? N : M, nx = transp ? M : N;
+  if (m == 0 || ny == 0) return 0;
+  RLH_REQUIRE(Y && (nx == 0 || (A && X)), "rlh_dense_apply: null pointer");
+  RLH_REQUIRE(lda >= (order == 0 ? N : M), "rlh_dense_apply: lda too small");
+  RLH_REQUIRE(ldx >= nx && ldy >= ny, "rlh_dense_apply: Matrix and vectors dimensions incompatible");
+  RLH_REQUIRE(m <= 65535 * 64, "rlh_dense_apply: too many vectors");
+  DenseArgs a;
+  a.A = A; a.lda = lda;
+  // Op(i,k): transp 0 -> A(i,k); transp 1 -> conj(A(k,i)).  Row-major A(i,k) = A[i*lda+k].
+  a.a_kcontig = ((order == 0) != (transp == 1)) ? 1 : 0;
+  a.conj_a = (transp == 1 && (dtype == RLH_C || dtype == RLH_Z)) ? 1 : 0;
+  a.ny = ny; a.nx = nx; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.m = (int)m;
+  switch (dtype) {
+    case RLH_S: return dense_impl<RLH_S>(a);
+    case RLH_D: return dense_impl<RLH_D>(a);
+    case RLH_C: return dense_impl<RLH_C>(a);
+    case RLH_Z: return dense_impl<RLH_Z>(a);
+  }
+  return 1;
+}

@@ -1,0 +1,507 @@
+// K1 Gram (X.dot(Y)), K2 dots, K2t transposed dots for gfx950.
+//
+// Gram: G = Y^H X is a contraction over the n rows of two tall-skinny blocks.
+// Each 256-thread workgroup streams 512-byte column segments (coalesced 16-byte
+// loads) of a row chunk into an LDS tile [vcol][row], the four waves then run
+// v_mfma_{f64,f32}_16x16x4 over disjoint row quarters of the tile with
+// conflict-free ds_read (column stride == 2 mod 32), accumulating a
+// (PI*16) x (PJ*16) panel of G in registers.  Loads of chunk t+1 are in flight
+// while chunk t is multiplied.  Per-workgroup partials are combined by a second,
+// deterministic kernel (fixed summation order => bitwise reproducible results).
+// Complex blocks are viewed as real blocks with twice the columns (re, im
+// de-interleaved on the way into LDS); the finalize kernel recombines
+// conj(y)*x = (RR + II) + i (RI - IR).
+//
+// Replaces: cublas?gemm(ConjTrans, NoTrans) + cudaMalloc/cudaMemcpy/cudaFree per call
+// (raleigh/algebra/dense_cublas.py:245-269), m blocking cublas?dot calls
+// (dense_cublas.py:233-243) and gemmBatched (dense_cublas.py:175-221).
+#include "common.h"
+
+namespace rlh {
+
+template <typename R> struct Mfma16;
+template <> struct Mfma16<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+  static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma16<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4)*4 + reg
+  static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+
+struct GramArgs {
+  const void *X, *Y;
+  int64_t ldx, ldy;   // in elements of T
+  int64_t n;          // rows
+  int mx, my;         // columns of T
+  int same;           // X and Y are the same window: read once
+  int npj;            // number of X panels
+  int64_t nchunks;
+  void *partials;     // [npanels][gridDim.x][VY][VX] reals
+};
+
+template <int DT, int PI, int PJ, bool ALIGNED>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+  using T = typename DType<DT>::T;
+  using R = typename DType<DT>::R;
+  using M = Mfma16<R>;
+  using acc_t = typename M::acc_t;
+  constexpr bool CPLX = DType<DT>::cplx;
+  constexpr int NC = CPLX ? 2 : 1;               // reals per element
+  constexpr int ROWS = 512 / (int)sizeof(R);     // rows per chunk (64 f64 / 128 f32)
+  constexpr int RPU = 16 / (int)sizeof(R);       // reals per 16-byte unit
+  constexpr int UPC = ROWS * NC / RPU;           // units per T-column per chunk
+  constexpr int VY = PI * 16, VX = PJ * 16;      // real (virtual) columns per panel
+  constexpr int CY = VY / NC, CX = VX / NC;      // T columns per panel
+  constexpr int S = ROWS + 2;                    // LDS column stride in reals (== 2 mod 32)
+  constexpr int UNITS_MAX = (CY + CX) * UPC;
+  constexpr int UPT = (UNITS_MAX + 255) / 256;   // units per thread
+
+  __shared__ __attribute__((aligned(16))) R lds[(VY + VX) * S];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int panel = blockIdx.y;
+  const int pi = panel / a.npj, pj = panel % a.npj;
+  const bool same_panel = a.same && (pi == pj) && (PI == PJ);
+  const int cy0 = pi * CY, cx0 = pj * CX;        // first T column of the panels
+  const int units_y = same_panel ? 0 : CY * UPC;
+  const int nunits = units_y + CX * UPC;
+  R *ldsY = same_panel ? (lds + VY * S) : lds;
+  R *ldsX = lds + VY * S;
+
+  const R *Xr = reinterpret_cast<const R *>(a.X);
+  const R *Yr = reinterpret_cast<const R *>(a.Y);
+
+  struct alignas(16) U16 { R v[RPU]; };
+  U16 regs[UPT];
+
+  auto load_chunk = [&](int64_t chunk) {
+    const int64_t row0 = chunk * ROWS;
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const int u = tid + q * 256;
+      U16 val;
+#pragma unroll
+      for (int e = 0; e < RPU; ++e) val.v[e] = (R)0;
+      if (u < nunits) {
+        const bool isY = u < units_y;
+        const int uu = isY ? u : u - units_y;
+        const int col = uu / UPC, k = uu % UPC;
+        const int gcol = (isY ? cy0 : cx0) + col;
+        const int mcols = isY ? a.my : a.mx;
+        const int64_t ld = isY ? a.ldy : a.ldx;
+        const R *base = isY ? Yr : Xr;
+        // real offset inside the column of the first real of this unit
+        const int64_t roff = row0 * NC + (int64_t)k * RPU;
+        const int64_t rend = a.n * NC;             // reals in a column
+        if (gcol < mcols && roff < rend) {
+          const R *p = base + ((int64_t)gcol * ld) * NC + roff;
+          if (ALIGNED && roff + RPU <= rend) {
+            val = *reinterpret_cast<const U16 *>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < RPU; ++e)
+              if (roff + e < rend) val.v[e] = p[e];
+          }
+        }
+      }
+      regs[q] = val;
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const int u = tid + q * 256;
+      if (u < nunits) {
+        const bool isY = u < units_y;
+        const int uu = isY ? u : u - units_y;
+        const int col = uu / UPC, k = uu % UPC;
+        R *dst = isY ? ldsY : ldsX;
+        if constexpr (!CPLX) {
+          R *d = dst + col * S + k * RPU;
+          if constexpr (sizeof(R) == 8) {
+            *reinterpret_cast<U16 *>(d) = regs[q];       // ds_write_b128 (S*8 % 16 == 0)
+          } else {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 lo = {(float)regs[q].v[0], (float)regs[q].v[1]};
+            f2 hi = {(float)regs[q].v[RPU > 2 ? 2 : 0], (float)regs[q].v[RPU > 3 ? 3 : 1]};
+            reinterpret_cast<f2 *>(d)[0] = lo;           // 2 x ds_write_b64 (S*4 % 8 == 0)
+            reinterpret_cast<f2 *>(d)[1] = hi;
+          }
+        } else {
+          // unit holds RPU/2 complex rows: de-interleave into the re / im virtual columns
+          constexpr int CR = RPU / 2;                    // complex rows per unit (1 z, 2 c)
+          R *dre = dst + (2 * col) * S + k * CR;
+          R *dim = dre + S;
+          if constexpr (CR == 1) {
+            dre[0] = regs[q].v[0];
+            dim[0] = regs[q].v[1];
+          } else {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 re = {(float)regs[q].v[0], (float)regs[q].v[RPU > 2 ? 2 : 0]};
+            f2 im = {(float)regs[q].v[1], (float)regs[q].v[RPU > 3 ? 3 : 1]};
+            *reinterpret_cast<f2 *>(dre) = re;
+            *reinterpret_cast<f2 *>(dim) = im;
+          }
+        }
+      }
+    }
+  };
+
+  acc_t acc[PI][PJ];
+#pragma unroll
+  for (int i = 0; i < PI; ++i)
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) acc[i][j] = acc_t{(R)0, (R)0, (R)0, (R)0};
+
+  int64_t chunk = blockIdx.x;
+  if (chunk < a.nchunks) load_chunk(chunk);
+  const int fr = lane & 15, fk = lane >> 4;
+  for (; chunk < a.nchunks; chunk += gridDim.x) {
+    __syncthreads();                 // previous MFMA phase has finished reading the tile
+    store_chunk();
+    __syncthreads();
+    const int64_t next = chunk + gridDim.x;
+    if (next < a.nchunks) load_chunk(next);   // in flight during the MFMA phase
+    const int rbase = wave * (ROWS / 4);
+#pragma unroll 4
+    for (int ks = 0; ks < ROWS / 16; ++ks) {
+      const int row = rbase + ks * 4 + fk;
+      R fa[PI], fb[PJ];
+#pragma unroll
+      for (int i = 0; i < PI; ++i) fa[i] = ldsY[(i * 16 + fr) * S + row];
+#pragma unroll
+      for (int j = 0; j < PJ; ++j) fb[j] = ldsX[(j * 16 + fr) * S + row];
+#pragma unroll
+      for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) acc[i][j] = M::run(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  // ---- combine the four waves in a fixed order through LDS, then write the partial
+  __syncthreads();
+  constexpr int TILE = 256;   // reals per 16x16 tile
+  static_assert(PI * PJ * TILE <= (VY + VX) * S, "epilogue does not fit the staging tile");
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ii = i * 16 + M::out_row(lane, r), jj = j * 16 + (lane & 15);
+            R *p = &lds[ii * VX + jj];
+            *p = (w == 0) ? acc[i][j][r] : (*p + acc[i][j][r]);
+          }
+    }
+    __syncthreads();
+  }
+  R *out = reinterpret_cast<R *>(a.partials) + ((int64_t)panel * gridDim.x + blockIdx.x) * (VY * VX);
+  for (int e = tid; e < VY * VX; e += 256) out[e] = lds[e];
+}
+
+// Sums the per-workgroup partials in a fixed order (16 strided lanes per output, then a
+// serial 16-term sum) and writes the (my, mx) result; complex outputs recombine the four
+// real Gram entries conj(y)*x = (RR + II) + i (RI - IR).
+template <int DT>
+__global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int nbx, int npj, int VY, int VX, int my,
+                                                     int mx, void *out_) {
+  using T = typename DType<DT>::T;
+  using R = typename DType<DT>::R;
+  constexpr bool CPLX = DType<DT>::cplx;
+  constexpr int NCOMP = CPLX ? 4 : 1;
+  __shared__ double red[NCOMP][16][17];
+  const R *partials = reinterpret_cast<const R *>(partials_);
+  const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + o;
+  const bool valid = e < my * mx;
+  const int i = valid ? e / mx : 0, j = valid ? e % mx : 0;
+  const int64_t slab = (int64_t)VY * VX;
+#pragma unroll
+  for (int comp = 0; comp < NCOMP; ++comp) {
+    const int vi = CPLX ? 2 * i + (comp >> 1) : i;     // comp: 0 RR, 1 RI, 2 IR, 3 II
+    const int vj = CPLX ? 2 * j + (comp & 1) : j;
+    const int panel = (vi / VY) * npj + (vj / VX);
+    const R *p = partials + (int64_t)panel * nbx * slab + (vi % VY) * VX + (vj % VX);
+    double s = 0.0;
+    if (valid)
+      for (int b = l; b < nbx; b += 16) s += (double)p[(int64_t)b * slab];
+    red[comp][l][o] = s;
+  }
+  __syncthreads();
+  if (l == 0 && valid) {
+    double t[NCOMP];
+#pragma unroll
+    for (int comp = 0; comp < NCOMP; ++comp) {
+      double acc = 0.0;
+      for (int ll = 0; ll < 16; ++ll) acc += red[comp][ll][o];
+      t[comp] = acc;
+    }
+    T *out = reinterpret_cast<T *>(out_);
+    if constexpr (!CPLX) {
+      out[e] = (R)t[0];
+    } else {
+      out[e].re = (R)(t[0] + t[3]);
+      out[e].im = (R)(t[1] - t[2]);
+    }
+  }
+}
+
+// Resident workgroups per CU for one instantiation (registers + LDS), asked once.
+template <int DT, int PI, int PJ, bool ALIGNED>
+static int gram_blocks_per_cu() {
+  static int cached = 0;
+  if (cached == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED>, 256, 0) != hipSuccess ||
+        nb < 1)
+      nb = 1;
+    cached = nb > 8 ? 8 : nb;
+  }
+  return cached;
+}
+
+static inline int pick_tiles(int v) {   // 16x16 tiles per panel side: 1, 2 or 4
+  if (v <= 16) return 1;
+  if (v <= 32) return 2;
+  return 4;
+}
+
+template <int DT, int PI, int PJ, bool ALIGNED>
+static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, void *d_out) {
+  using R = typename DType<DT>::R;
+  Context &c = ctx();
+  constexpr int VY = PI * 16, VX = PJ * 16;
+  const int npanels = npi * npj;
+  // the grid is sized to what is resident at once: every workgroup strides over the row
+  // chunks, so a second, partially filled round of workgroups would only add a tail
+  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED>() / npanels;
+  if (nbx < 1) nbx = 1;
+  if (nbx > a.nchunks) nbx = a.nchunks;
+  const size_t part_bytes = sizeof(R) * VY * VX;
+  while (nbx > 1 && (size_t)nbx * npanels * part_bytes > kWorkspaceBytes) nbx /= 2;
+  RLH_REQUIRE((size_t)nbx * npanels * part_bytes <= kWorkspaceBytes,
+              "rlh_gram: %lld x %lld result exceeds the reduction workspace", (long long)my, (long long)mx);
+  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED>), dim3((unsigned)nbx, (unsigned)npanels), dim3(256), 0,
+                     c.stream, a);
+  RLH_HIP(hipGetLastError());
+  const int total = (int)(my * mx);
+  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 15) / 16), dim3(256), 0, c.stream, c.work, (int)nbx, npj, VY,
+                     VX, (int)my, (int)mx, d_out);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int DT>
+static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t my, const void *Y, int64_t ldy,
+                     void *d_out) {
+  using R = typename DType<DT>::R;
+  constexpr int NC = DType<DT>::cplx ? 2 : 1;
+  constexpr int ROWS = 512 / (int)sizeof(R);
+  Context &c = ctx();
+  const int vx = (int)mx * NC, vy = (int)my * NC;
+  const int PI = pick_tiles(vy), PJ = pick_tiles(vx);
+  const int npi = (vy + PI * 16 - 1) / (PI * 16), npj = (vx + PJ * 16 - 1) / (PJ * 16);
+  GramArgs a;
+  a.X = X; a.Y = Y; a.ldx = ldx; a.ldy = ldy; a.n = n; a.mx = (int)mx; a.my = (int)my;
+  a.same = (X == Y && ldx == ldy && mx == my) ? 1 : 0;
+  a.npj = npj; a.nchunks = (n + ROWS - 1) / ROWS; a.partials = c.work;
+  const int64_t es = dtype_size(DT);
+  const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
+#define RLH_GRAM_CASE(pi, pj)                                                              \
+  if (PI == pi && PJ == pj)                                                                \
+    return aligned ? gram_launch<DT, pi, pj, true>(a, npi, npj, my, mx, d_out)             \
+                   : gram_launch<DT, pi, pj, false>(a, npi, npj, my, mx, d_out);
+  RLH_GRAM_CASE(1, 1) RLH_GRAM_CASE(1, 2) RLH_GRAM_CASE(1, 4)
+  RLH_GRAM_CASE(2, 1) RLH_GRAM_CASE(2, 2) RLH_GRAM_CASE(2, 4)
+  RLH_GRAM_CASE(4, 1) RLH_GRAM_CASE(4, 2) RLH_GRAM_CASE(4, 4)
+#undef RLH_GRAM_CASE
+  set_error("rlh_gram: no kernel for panel %d x %d", PI, PJ);
+  return 1;
+}
+
+// ---------------------------------------------------------------- dots (K2)
+// One workgroup per (row block, column); deterministic two-stage reduction.
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void dots_kernel(const T *X, int64_t ldx, const T *Y, int64_t ldy, int64_t n,
+                                                   T *partials, int nbx) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int col = blockIdx.y;
+  const T *x = X + (int64_t)col * ldx;
+  const T *y = Y + (int64_t)col * ldy;
+  T acc = zero_of(T{});
+  const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
+    if (ALIGNED && r + VEC <= n) {
+      struct alignas(16) V { T v[VEC]; };
+      const V xv = *reinterpret_cast<const V *>(x + r);
+      const V yv = *reinterpret_cast<const V *>(y + r);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) fma_conj_acc(acc, yv.v[e], xv.v[e]);
+    } else {
+      for (int e = 0; e < VEC && r + e < n; ++e) fma_conj_acc(acc, y[r + e], x[r + e]);
+    }
+  }
+  __shared__ T red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = add_of(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[(int64_t)col * nbx + blockIdx.x] = red[0];
+}
+
+template <typename T>
+__global__ void dots_finalize(const T *partials, int nbx, int m, T *out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= m) return;
+  T s = zero_of(T{});
+  for (int b = 0; b < nbx; ++b) s = add_of(s, partials[(int64_t)col * nbx + b]);
+  out[col] = s;
+}
+
+template <int DT>
+static int dots_impl(int64_t n, int64_t m, const void *X, int64_t ldx, const void *Y, int64_t ldy, void *d_out) {
+  using T = typename DType<DT>::T;
+  Context &c = ctx();
+  constexpr int VEC = 16 / (int)sizeof(T);
+  int64_t nbx = (n + 256 * VEC * 4 - 1) / (256 * VEC * 4);     // >= 4 vector loads per thread
+  const int64_t cap = ((int64_t)c.num_cu * 8 + m - 1) / m;
+  if (nbx > cap) nbx = cap;
+  if (nbx < 1) nbx = 1;
+  RLH_REQUIRE((size_t)nbx * m * sizeof(T) <= kWorkspaceBytes, "rlh_dots: too many columns");
+  const bool aligned = aligned16(X, ldx, sizeof(T)) && aligned16(Y, ldy, sizeof(T));
+  dim3 grid((unsigned)nbx, (unsigned)m);
+  if (aligned)
+    hipLaunchKernelGGL((dots_kernel<T, true>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
+                       n, (T *)c.work, (int)nbx);
+  else
+    hipLaunchKernelGGL((dots_kernel<T, false>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
+                       n, (T *)c.work, (int)nbx);
+  RLH_HIP(hipGetLastError());
+  hipLaunchKernelGGL((dots_finalize<T>), dim3(((int)m + 63) / 64), dim3(64), 0, c.stream, (const T *)c.work,
+                     (int)nbx, (int)m, (T *)d_out);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- transposed dots (K2t)
+template <typename T>
+__global__ __launch_bounds__(256) void dots_transp_kernel(const T *X, int64_t ldx, const T *Y, int64_t ldy,
+                                                          int64_t n, int m, T *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    T acc = zero_of(T{});
+    for (int i = 0; i < m; ++i) fma_conj_acc(acc, Y[r + (int64_t)i * ldy], X[r + (int64_t)i * ldx]);
+    out[r] = acc;
+  }
+}
+
+template <int DT>
+static int dots_transp_impl(int64_t n, int64_t m, const void *X, int64_t ldx, const void *Y, int64_t ldy,
+                            void *d_out) {
+  using T = typename DType<DT>::T;
+  Context &c = ctx();
+  int64_t nb = (n + 255) / 256;
+  if (nb > (int64_t)c.num_cu * 8) nb = (int64_t)c.num_cu * 8;
+  hipLaunchKernelGGL((dots_transp_kernel<T>), dim3((unsigned)nb), dim3(256), 0, c.stream, (const T *)X, ldx,
+                     (const T *)Y, ldy, n, (int)m, (T *)d_out);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rlh
+
+using namespace rlh;
+
+#define RLH_DISPATCH(dt, fn, ...)                              \
+  switch (dt) {                                                \
+    case RLH_S: rc = fn<RLH_S>(__VA_ARGS__); break;            \
+    case RLH_D: rc = fn<RLH_D>(__VA_ARGS__); break;            \
+    case RLH_C: rc = fn<RLH_C>(__VA_ARGS__); break;            \
+    case RLH_Z: rc = fn<RLH_Z>(__VA_ARGS__); break;            \
+    default: rlh::set_error("unknown dtype %d", dt); rc = 1;   \
+  }
+
+extern "C" {
+
+int rlh_gram(int dtype, int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t my, const void *Y, int64_t ldy,
+             void *d_out, void *h_out) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_gram: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && mx >= 0 && my >= 0, "rlh_gram: negative size");
+  RLH_REQUIRE(mx <= 32768 && my <= 32768, "rlh_gram: more than 32768 vectors in a window");
+  if (mx == 0 || my == 0) return 0;
+  RLH_REQUIRE(X && Y, "rlh_gram: null block pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_gram: leading dimension smaller than n");
+  RLH_REQUIRE(d_out || h_out, "rlh_gram: no output buffer");
+  const size_t bytes = (size_t)(mx * my * dtype_size(dtype));
+  if (!d_out) {
+    if (int rc = ensure_result(bytes)) return rc;
+    d_out = ctx().result_d;
+  }
+  int rc = 0;
+  if (n == 0) {
+    RLH_HIP(hipMemsetAsync(d_out, 0, bytes, ctx().stream));
+  } else {
+    RLH_DISPATCH(dtype, gram_impl, n, mx, X, ldx, my, Y, ldy, d_out)
+  }
+  if (rc) return rc;
+  if (h_out) return fetch_result(h_out, d_out, bytes);
+  return 0;
+}
+
+int rlh_dots(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, const void *Y, int64_t ldy, void *d_out,
+             void *h_out) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_dots: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_dots: negative size");
+  RLH_REQUIRE(m <= 32768, "rlh_dots: more than 32768 vectors in a window");
+  if (m == 0) return 0;
+  RLH_REQUIRE(X && Y, "rlh_dots: null block pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_dots: leading dimension smaller than n");
+  RLH_REQUIRE(d_out || h_out, "rlh_dots: no output buffer");
+  const size_t bytes = (size_t)(m * dtype_size(dtype));
+  if (!d_out) {
+    if (int rc = ensure_result(bytes)) return rc;
+    d_out = ctx().result_d;
+  }
+  int rc = 0;
+  if (n == 0) {
+    RLH_HIP(hipMemsetAsync(d_out, 0, bytes, ctx().stream));
+  } else {
+    RLH_DISPATCH(dtype, dots_impl, n, m, X, ldx, Y, ldy, d_out)
+  }
+  if (rc) return rc;
+  if (h_out) return fetch_result(h_out, d_out, bytes);
+  return 0;
+}
+
+int rlh_dots_transp(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, const void *Y, int64_t ldy,
+                    void *d_out) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_dots_transp: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_dots_transp: negative size");
+  if (n == 0) return 0;
+  RLH_REQUIRE(d_out, "rlh_dots_transp: null output");
+  RLH_REQUIRE(m == 0 || (X && Y), "rlh_dots_transp: null block pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_dots_transp: leading dimension smaller than n");
+  int rc = 0;
+  RLH_DISPATCH(dtype, dots_transp_impl, n, m, X, ldx, Y, ldy, d_out)
+  return rc;
+}
+
+}  // extern "C"

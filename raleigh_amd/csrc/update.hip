@@ -1,0 +1,418 @@
+// K3/K4 block update Out = beta*Out + alpha * X * Q and the column-wise
+// elementwise kernels K5-K8 (axpy, column axpy, copy / gather, scale, conj).
+//
+// Block update: one lane owns one row.  The k x m coefficient matrix lives in
+// device memory (staged through the pinned ring) and is read with wave-uniform
+// indices, so it arrives through the scalar cache into SGPRs and feeds
+// v_fma_{f32,f64} directly; X columns are read and Out columns written with
+// fully coalesced wave accesses.  Arithmetic intensity at m = k = 32 fp64 is
+// 4 flop/byte: the VALU needs ~31% utilisation at the HBM rate, so the kernel is
+// HBM-bound; no LDS is needed because nothing is shared between lanes.
+//
+// Replaces: cudaMalloc + H2D + cublas?gemm(NoTrans, Trans|NoTrans) + cudaFree
+// (raleigh/algebra/dense_cublas.py:271-342), m axpy / scal / copy calls
+// (dense_cublas.py:133-172, 343-350).
+#include "common.h"
+
+namespace rlh {
+
+constexpr int kUnrollK = 4;
+
+template <typename T, int JT, bool BETA>
+__global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__ X, int64_t ldx,
+                                                           T *__restrict__ Out, int64_t ldo,
+                                                           const T *__restrict__ Q, int ldq, int64_t n, int k,
+                                                           int m) {
+  const int j0 = blockIdx.y * JT;
+  const int jv = (m - j0) < JT ? (m - j0) : JT;      // valid output columns of this panel
+  const T *__restrict__ Qp = Q + j0;
+  T *__restrict__ Op = Out + (int64_t)j0 * ldo;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride) {
+    T acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      acc[j] = zero_of(T{});
+      if (BETA && j < jv) acc[j] = Op[row + (int64_t)j * ldo];
+    }
+    for (int i = 0; i < k; i += kUnrollK) {
+      T x[kUnrollK];
+#pragma unroll
+      for (int u = 0; u < kUnrollK; ++u) {
+        const int col = (i + u) < k ? (i + u) : (k - 1);     // Q rows >= k are zero
+        x[u] = X[row + (int64_t)col * ldx];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnrollK; ++u)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) fma_acc(acc[j], x[u], Qp[(i + u) * ldq + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      if (j < jv) Op[row + (int64_t)j * ldo] = acc[j];
+  }
+}
+
+template <typename T> struct HostScalar;
+template <> struct HostScalar<float>  { static float  mul(const double *a, float q)  { return (float)(a[0] * q); } };
+template <> struct HostScalar<double> { static double mul(const double *a, double q) { return a[0] * q; } };
+template <> struct HostScalar<c32> {
+  static c32 mul(const double *a, c32 q) {
+    return c32{(float)(a[0] * q.re - a[1] * q.im), (float)(a[0] * q.im + a[1] * q.re)};
+  }
+};
+template <> struct HostScalar<c64> {
+  static c64 mul(const double *a, c64 q) { return c64{a[0] * q.re - a[1] * q.im, a[0] * q.im + a[1] * q.re}; }
+};
+
+template <typename T, int JT>
+static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
+                         int beta) {
+  Context &c = ctx();
+  int64_t nbx = (n + 255) / 256;
+  const int64_t cap = (int64_t)c.num_cu * 8;
+  if (nbx > cap) nbx = cap;
+  dim3 grid((unsigned)nbx, (unsigned)((m + JT - 1) / JT));
+  if (beta)
+    hipLaunchKernelGGL((block_update_kernel<T, JT, true>), grid, dim3(256), 0, c.stream, X, ldx, Out, ldo, Qd, ldq, n,
+                       k, m);
+  else
+    hipLaunchKernelGGL((block_update_kernel<T, JT, false>), grid, dim3(256), 0, c.stream, X, ldx, Out, ldo, Qd, ldq,
+                       n, k, m);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int DT>
+static int block_update_impl(int64_t n, int64_t k, const void *X_, int64_t ldx, int64_t m, void *Out_, int64_t ldo,
+                             const void *q_, int64_t q_rs, int64_t q_cs, const double *alpha, int beta) {
+  using T = typename DType<DT>::T;
+  constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
+  const T *X = (const T *)X_;
+  T *Out = (T *)Out_;
+  const T *q = (const T *)q_;
+  const int JT = (m <= 8) ? 8 : ((m <= 16 || JTMAX == 16) ? 16 : 32);
+  const int64_t mpad = (m + JT - 1) / JT * JT;
+  // rows of Q per launch so that the padded coefficient block fits one ring slot
+  int64_t kmax = (int64_t)(kRingSlotBytes / (mpad * sizeof(T))) / kUnrollK * kUnrollK;
+  RLH_REQUIRE(kmax >= kUnrollK, "rlh_block_update: %lld output vectors exceed the staging slot", (long long)m);
+  if (kmax > 1024) kmax = 1024;
+  for (int64_t k0 = 0; k0 < k || k0 == 0; k0 += kmax) {
+    const int64_t kk = (k - k0) < kmax ? (k - k0) : kmax;
+    const int64_t kpad = (kk + kUnrollK - 1) / kUnrollK * kUnrollK;
+    int slot; void *h, *d;
+    if (int rc = ring_acquire((size_t)(kpad * mpad) * sizeof(T), &slot, &h, &d)) return rc;
+    T *qh = (T *)h;
+    memset(qh, 0, (size_t)(kpad * mpad) * sizeof(T));
+    for (int64_t i = 0; i < kk; ++i)
+      for (int64_t j = 0; j < m; ++j) qh[i * mpad + j] = HostScalar<T>::mul(alpha, q[(k0 + i) * q_rs + j * q_cs]);
+    if (int rc = ring_commit(slot, (size_t)(kpad * mpad) * sizeof(T))) return rc;
+    const int b = (k0 == 0) ? beta : 1;
+    int rc;
+    if (kk == 0) {       // k == 0: Out = beta * Out
+      if (!b) {
+        for (int64_t j = 0; j < m; ++j)
+          RLH_HIP(hipMemsetAsync(Out + j * ldo, 0, (size_t)n * sizeof(T), ctx().stream));
+      }
+      rc = 0;
+    } else if (JT == 8) {
+      rc = launch_update<T, 8>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk, (int)m, b);
+    } else if (JT == 16) {
+      rc = launch_update<T, 16>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk, (int)m, b);
+    } else {
+      rc = launch_update<T, (JTMAX == 32 ? 32 : 16)>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk,
+                                                     (int)m, b);
+    }
+    if (rc) return rc;
+    if (int rc2 = ring_release(slot)) return rc2;
+    if (k == 0) break;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- column-wise elementwise kernels
+// grid = (row blocks, columns); VEC elements (16 bytes) per lane when aligned.
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void axpy_cols_kernel(const T *__restrict__ X, int64_t ldx, T *__restrict__ Y,
+                                                        int64_t ldy, const T *__restrict__ s, int64_t n) {
+  constexpr int VEC = ALIGNED ? 16 / (int)sizeof(T) : 1;
+  struct alignas(ALIGNED ? 16 : alignof(T)) V { T v[VEC]; };
+  const int col = blockIdx.y;
+  const T a = s[col];
+  const T *x = X + (int64_t)col * ldx;
+  T *y = Y + (int64_t)col * ldy;
+  const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
+    if (r + VEC <= n) {
+      const V xv = *reinterpret_cast<const V *>(x + r);
+      V yv = *reinterpret_cast<const V *>(y + r);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) fma_acc(yv.v[e], a, xv.v[e]);
+      *reinterpret_cast<V *>(y + r) = yv;
+    } else {
+      for (int e = 0; e < VEC && r + e < n; ++e) {
+        T t = y[r + e];
+        fma_acc(t, a, x[r + e]);
+        y[r + e] = t;
+      }
+    }
+  }
+}
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void scale_cols_kernel(T *__restrict__ X, int64_t ldx, const T *__restrict__ s,
+                                                         int64_t n) {
+  constexpr int VEC = ALIGNED ? 16 / (int)sizeof(T) : 1;
+  struct alignas(ALIGNED ? 16 : alignof(T)) V { T v[VEC]; };
+  const int col = blockIdx.y;
+  const T a = s[col];
+  T *x = X + (int64_t)col * ldx;
+  const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
+    if (r + VEC <= n) {
+      V xv = *reinterpret_cast<const V *>(x + r);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) xv.v[e] = mul_of(xv.v[e], a);
+      *reinterpret_cast<V *>(x + r) = xv;
+    } else {
+      for (int e = 0; e < VEC && r + e < n; ++e) x[r + e] = mul_of(x[r + e], a);
+    }
+  }
+}
+
+// Copies columns as raw words of W bytes (16 when everything is 16-byte aligned, else the
+// element's real size); ind == nullptr copies column j to column j.
+template <typename W>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const W *__restrict__ X, int64_t ldx_w, W *__restrict__ Y,
+                                                        int64_t ldy_w, const int64_t *__restrict__ ind,
+                                                        int64_t n_w) {
+  const int col = blockIdx.y;
+  const int64_t src = ind ? ind[col] : col;
+  const W *x = X + src * ldx_w;
+  W *y = Y + (int64_t)col * ldy_w;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_w; r += stride) y[r] = x[r];
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void conj_kernel(R *X, int64_t ldx_r, int64_t n) {
+  R *x = X + (int64_t)blockIdx.y * ldx_r;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) x[2 * r + 1] = -x[2 * r + 1];
+}
+
+static inline unsigned row_blocks(int64_t items, int64_t m) {
+  Context &c = ctx();
+  int64_t nb = (items + 256 * 4 - 1) / (256 * 4);            // ~4 items per lane
+  const int64_t cap = ((int64_t)c.num_cu * 16 + m - 1) / m;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return (unsigned)nb;
+}
+
+// stages m per-column coefficients of type T into the ring
+template <typename T, typename F>
+static int stage_coeffs(int64_t m, F fill, int *slot, const T **d) {
+  void *h, *dv;
+  if (int rc = ring_acquire((size_t)m * sizeof(T), slot, &h, &dv)) return rc;
+  T *p = (T *)h;
+  for (int64_t i = 0; i < m; ++i) p[i] = fill(i);
+  if (int rc = ring_commit(*slot, (size_t)m * sizeof(T))) return rc;
+  *d = (const T *)dv;
+  return 0;
+}
+
+template <int DT>
+static int axpy_cols_impl(int64_t n, int64_t m, const void *s_, bool broadcast, const void *X, int64_t ldx, void *Y,
+                          int64_t ldy) {
+  using T = typename DType<DT>::T;
+  const T *s = (const T *)s_;
+  int slot; const T *sd;
+  if (int rc = stage_coeffs<T>(m, [&](int64_t i) { return broadcast ? s[0] : s[i]; }, &slot, &sd)) return rc;
+  const bool al = aligned16(X, ldx, sizeof(T)) && aligned16(Y, ldy, sizeof(T));
+  const int vec = al ? 16 / (int)sizeof(T) : 1;
+  dim3 grid(row_blocks((n + vec - 1) / vec, m), (unsigned)m);
+  if (al)
+    hipLaunchKernelGGL((axpy_cols_kernel<T, true>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y, ldy,
+                       sd, n);
+  else
+    hipLaunchKernelGGL((axpy_cols_kernel<T, false>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y,
+                       ldy, sd, n);
+  RLH_HIP(hipGetLastError());
+  return ring_release(slot);
+}
+
+template <int DT>
+static int scale_cols_impl(int64_t n, int64_t m, const double *s, int mode, void *X, int64_t ldx) {
+  using T = typename DType<DT>::T;
+  using R = typename DType<DT>::R;
+  constexpr bool CPLX = DType<DT>::cplx;
+  int slot; const T *sd;
+  auto fill = [&](int64_t i) -> T {
+    double re = CPLX ? s[2 * i] : s[i], im = CPLX ? s[2 * i + 1] : 0.0;
+    if (mode == 0) {                       // divide, skipping zeros (dense_numpy.py:49-52)
+      const double d = re * re + im * im;
+      if (d == 0.0) { re = 1.0; im = 0.0; }
+      else if (im == 0.0) { re = 1.0 / re; }
+      else { const double r2 = re / d, i2 = -im / d; re = r2; im = i2; }
+    }
+    if constexpr (CPLX) return T{(R)re, (R)im};
+    else return (T)re;
+  };
+  if (int rc = stage_coeffs<T>(m, fill, &slot, &sd)) return rc;
+  const bool al = aligned16(X, ldx, sizeof(T));
+  const int vec = al ? 16 / (int)sizeof(T) : 1;
+  dim3 grid(row_blocks((n + vec - 1) / vec, m), (unsigned)m);
+  if (al)
+    hipLaunchKernelGGL((scale_cols_kernel<T, true>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
+  else
+    hipLaunchKernelGGL((scale_cols_kernel<T, false>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
+  RLH_HIP(hipGetLastError());
+  return ring_release(slot);
+}
+
+static int copy_cols_impl(int dtype, int64_t n, int64_t m, const int64_t *ind, const void *X, int64_t ldx, void *Y,
+                          int64_t ldy) {
+  const int64_t es = dtype_size(dtype);
+  int slot = -1;
+  const int64_t *indd = nullptr;
+  if (ind) {
+    if (int rc = stage_coeffs<int64_t>(m, [&](int64_t i) { return ind[i]; }, &slot, &indd)) return rc;
+  }
+  const bool al = aligned16(X, ldx, es) && aligned16(Y, ldy, es) && ((n * es) % 16 == 0);
+  if (al) {
+    typedef struct alignas(16) { uint32_t w[4]; } W16;
+    const int64_t nw = n * es / 16;
+    dim3 grid(row_blocks(nw, m), (unsigned)m);
+    hipLaunchKernelGGL((copy_cols_kernel<W16>), grid, dim3(256), 0, ctx().stream, (const W16 *)X, ldx * es / 16,
+                       (W16 *)Y, ldy * es / 16, indd, nw);
+  } else if (es % 8 == 0) {
+    const int64_t nw = n * es / 8;
+    dim3 grid(row_blocks(nw, m), (unsigned)m);
+    hipLaunchKernelGGL((copy_cols_kernel<uint64_t>), grid, dim3(256), 0, ctx().stream, (const uint64_t *)X,
+                       ldx * es / 8, (uint64_t *)Y, ldy * es / 8, indd, nw);
+  } else {
+    dim3 grid(row_blocks(n, m), (unsigned)m);
+    hipLaunchKernelGGL((copy_cols_kernel<uint32_t>), grid, dim3(256), 0, ctx().stream, (const uint32_t *)X, ldx,
+                       (uint32_t *)Y, ldy, indd, n);
+  }
+  RLH_HIP(hipGetLastError());
+  if (slot >= 0) return ring_release(slot);
+  return 0;
+}
+
+}  // namespace rlh
+
+using namespace rlh;
+
+#define RLH_DISPATCH(dt, fn, ...)                              \
+  switch (dt) {                                                \
+    case RLH_S: rc = fn<RLH_S>(__VA_ARGS__); break;            \
+    case RLH_D: rc = fn<RLH_D>(__VA_ARGS__); break;            \
+    case RLH_C: rc = fn<RLH_C>(__VA_ARGS__); break;            \
+    case RLH_Z: rc = fn<RLH_Z>(__VA_ARGS__); break;            \
+    default: rlh::set_error("unknown dtype %d", dt); rc = 1;   \
+  }
+
+static bool overlaps(const void *a, int64_t a_bytes, const void *b, int64_t b_bytes) {
+  const char *pa = (const char *)a, *pb = (const char *)b;
+  return pa < pb + b_bytes && pb < pa + a_bytes;
+}
+
+extern "C" {
+
+int rlh_block_update(int dtype, int64_t n, int64_t k, const void *X, int64_t ldx, int64_t m, void *Out, int64_t ldo,
+                     const void *q, int64_t q_rs, int64_t q_cs, const double *alpha, int beta) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_block_update: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && k >= 0 && m >= 0, "rlh_block_update: negative size");
+  RLH_REQUIRE(beta == 0 || beta == 1, "rlh_block_update: beta must be 0 or 1");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(Out && alpha, "rlh_block_update: null pointer");
+  RLH_REQUIRE(k == 0 || (X && q), "rlh_block_update: null pointer");
+  RLH_REQUIRE(ldo >= n && (k == 0 || ldx >= n), "rlh_block_update: leading dimension smaller than n");
+  const int64_t es = dtype_size(dtype);
+  RLH_REQUIRE(k == 0 || !overlaps(X, ((k - 1) * ldx + n) * es, Out, ((m - 1) * ldo + n) * es),
+              "rlh_block_update: output window overlaps the input window");
+  int rc = 0;
+  RLH_DISPATCH(dtype, block_update_impl, n, k, X, ldx, m, Out, ldo, q, q_rs, q_cs, alpha, beta)
+  return rc;
+}
+
+int rlh_axpy(int dtype, int64_t n, int64_t m, const double *alpha, const void *X, int64_t ldx, void *Y, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_axpy: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_axpy: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(alpha && X && Y, "rlh_axpy: null pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_axpy: leading dimension smaller than n");
+  float sf[2] = {(float)alpha[0], (float)alpha[1]};
+  const void *s = (dtype == RLH_S || dtype == RLH_C) ? (const void *)sf : (const void *)alpha;
+  int rc = 0;
+  RLH_DISPATCH(dtype, axpy_cols_impl, n, m, s, true, X, ldx, Y, ldy)
+  return rc;
+}
+
+int rlh_axpy_cols(int dtype, int64_t n, int64_t m, const void *s, const void *X, int64_t ldx, void *Y, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_axpy_cols: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_axpy_cols: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(s && X && Y, "rlh_axpy_cols: null pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_axpy_cols: leading dimension smaller than n");
+  int rc = 0;
+  RLH_DISPATCH(dtype, axpy_cols_impl, n, m, s, false, X, ldx, Y, ldy)
+  return rc;
+}
+
+int rlh_copy(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_copy: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_copy: negative size");
+  if (n == 0 || m == 0 || (X == Y && ldx == ldy)) return 0;
+  RLH_REQUIRE(X && Y, "rlh_copy: null pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_copy: leading dimension smaller than n");
+  return copy_cols_impl(dtype, n, m, nullptr, X, ldx, Y, ldy);
+}
+
+int rlh_copy_cols(int dtype, int64_t n, int64_t m, const int64_t *ind, const void *Xall, int64_t ldx, void *Y,
+                  int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_copy_cols: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_copy_cols: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(ind && Xall && Y, "rlh_copy_cols: null pointer");
+  RLH_REQUIRE(ldx >= n && ldy >= n, "rlh_copy_cols: leading dimension smaller than n");
+  for (int64_t i = 0; i < m; ++i) RLH_REQUIRE(ind[i] >= 0, "rlh_copy_cols: negative index");
+  return copy_cols_impl(dtype, n, m, ind, Xall, ldx, Y, ldy);
+}
+
+int rlh_scale_cols(int dtype, int64_t n, int64_t m, const double *s, int mode, void *X, int64_t ldx) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_scale_cols: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_scale_cols: negative size");
+  RLH_REQUIRE(mode == 0 || mode == 1, "rlh_scale_cols: mode must be 0 (divide) or 1 (multiply)");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(s && X, "rlh_scale_cols: null pointer");
+  RLH_REQUIRE(ldx >= n, "rlh_scale_cols: leading dimension smaller than n");
+  int rc = 0;
+  RLH_DISPATCH(dtype, scale_cols_impl, n, m, s, mode, X, ldx)
+  return rc;
+}
+
+int rlh_conj(int dtype, int64_t n, int64_t m, void *X, int64_t ldx) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_conj: unknown dtype %d", dtype);
+  if (dtype == RLH_S || dtype == RLH_D || n <= 0 || m <= 0) return 0;
+  RLH_REQUIRE(X && ldx >= n, "rlh_conj: bad arguments");
+  dim3 grid(row_blocks(n, m), (unsigned)m);
+  if (dtype == RLH_C)
+    hipLaunchKernelGGL((conj_kernel<float>), grid, dim3(256), 0, ctx().stream, (float *)X, 2 * ldx, n);
+  else
+    hipLaunchKernelGGL((conj_kernel<double>), grid, dim3(256), 0, ctx().stream, (double *)X, 2 * ldx, n);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""A stand-in for librlhip.so that runs every C-ABI entry point on HOST memory
+through the CPU oracle.  TEST INFRASTRUCTURE ONLY: it lets the CPU-only test
+tier exercise the host logic of raleigh_amd (selection windows, strides,
+padding, sharding, the block-JCG driver) without a GPU.  "Device" pointers are
+plain host addresses.  The product never imports this module.
+"""
+
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+
+from oracle import ops
+
+_DT = {0: np.float32, 1: np.float64, 2: np.complex64, 3: np.complex128}
+
+
+def _addr(x):
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    if isinstance(x, ctypes.c_void_p):
+        return x.value or 0
+    if hasattr(x, 'value'):
+        return int(x.value or 0)
+    raise TypeError('cannot take the address of %r' % (x,))
+
+
+def _flat(ptr, dtype, count):
+    ptr = _addr(ptr)
+    dtype = np.dtype(dtype)
+    if count == 0:
+        return np.zeros((0,), dtype=dtype)
+    buf = (ctypes.c_char * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+def _block(ptr, code, n, m, ld):
+    """(m, n) view (one vector per row) of a column-major n x m block with leading dimension ld."""
+    dt = np.dtype(_DT[code])
+    if m == 0 or n == 0:
+        return np.zeros((m, n), dtype=dt)
+    flat = _flat(ptr, dt, (m - 1) * ld + n)
+    return np.lib.stride_tricks.as_strided(flat, shape=(m, n), strides=(ld * dt.itemsize, dt.itemsize))
+
+
+class _Csr:
+    def __init__(self, mat, code):
+        self.mat, self.code = mat, code
+
+
+class FakeLib:
+    def __init__(self):
+        self._mem = {}
+        self._err = b''
+        self._csr = {}
+        self._next_handle = 1
+        self.calls = {}
+        self.initialised = None
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    def _fail(self, msg):
+        self._err = msg.encode()
+        return 1
+
+    # ---- context
+    def rlh_version(self):
+        return 100
+
+    def rlh_last_error(self):
+        return self._err
+
+    def rlh_device_count(self, p):
+        p._obj.value = 1
+        return 0
+
+    def rlh_init(self, device):
+        self.initialised = device
+        return 0
+
+    def rlh_finalize(self):
+        return 0
+
+    def rlh_set_stream(self, s):
+        return 0
+
+    def rlh_sync(self):
+        return 0
+
+    def rlh_mem_info(self, f, t):
+        return 0
+
+    # ---- memory
+    def rlh_malloc(self, pp, nbytes):
+        buf = ctypes.create_string_buffer(max(int(nbytes), 1))
+        addr = ctypes.addressof(buf)
+        self._mem[addr] = buf
+        pp._obj.value = addr
+        return 0
+
+    def rlh_free(self, p):
+        self._mem.pop(_addr(p), None)
+        return 0
+
+    def rlh_memset(self, p, value, nbytes):
+        ctypes.memset(_addr(p), value, int(nbytes))
+        return 0
+
+    def rlh_h2d(self, d, h, nbytes):
+        ctypes.memmove(_addr(d), _addr(h), int(nbytes))
+        return 0
+
+    rlh_d2h = rlh_h2d
+    rlh_d2d = rlh_h2d
+
+    def rlh_copy2d(self, dst, dpitch, src, spitch, width, rows, kind):
+        d, s = _addr(dst), _addr(src)
+        for r in range(int(rows)):
+            ctypes.memmove(d + r * dpitch, s + r * spitch, int(width))
+        return 0
+
+    # ---- reductions
+    def rlh_gram(self, code, n, mx, X, ldx, my, Y, ldy, d_out, h_out):
+        self._count('gram')
+        if mx == 0 or my == 0:
+            return 0
+        if ldx < n or ldy < n:
+            return self._fail('rlh_gram: leading dimension smaller than n')
+        g = ops.gram(_block(X, code, n, mx, ldx), _block(Y, code, n, my, ldy)).astype(_DT[code])
+        for out in (d_out, h_out):
+            if _addr(out):
+                _flat(out, _DT[code], my * mx)[:] = g.ravel()
+        return 0
+
+    def rlh_dots(self, code, n, m, X, ldx, Y, ldy, d_out, h_out):
+        self._count('dots')
+        if m == 0:
+            return 0
+        v = ops.dots(_block(X, code, n, m, ldx), _block(Y, code, n, m, ldy)).astype(_DT[code])
+        for out in (d_out, h_out):
+            if _addr(out):
+                _flat(out, _DT[code], m)[:] = v
+        return 0
+
+    def rlh_dots_transp(self, code, n, m, X, ldx, Y, ldy, d_out):
+        self._count('dots_transp')
+        if n == 0:
+            return 0
+        w = ops.dots_transp(_block(X, code, n, m, ldx), _block(Y, code, n, m, ldy))
+        _flat(d_out, _DT[code], n)[:] = w
+        return 0
+
+    # ---- updates
+    def rlh_block_update(self, code, n, k, X, ldx, m, Out, ldo, q, q_rs, q_cs, alpha, beta):
+        self._count('block_update')
+        if n == 0 or m == 0:
+            return 0
+        dt = np.dtype(_DT[code])
+        a = _flat(alpha, np.float64, 2)
+        al = complex(a[0], a[1]) if dt.kind == 'c' else a[0]
+        out = _block(Out, code, n, m, ldo)
+        if k == 0:
+            if not beta:
+                out[:, :] = 0
+            return 0
+        span = (k - 1) * q_rs + (m - 1) * q_cs + 1
+        qf = _flat(q, dt, span)
+        qm = np.lib.stride_tricks.as_strided(qf, shape=(k, m),
+                                             strides=(q_rs * dt.itemsize, q_cs * dt.itemsize))
+        x = _block(X, code, n, k, ldx)
+        upd = (al * qm).T @ x
+        out[:, :] = (out + upd if beta else upd).astype(dt)
+        return 0
+
+    def rlh_axpy(self, code, n, m, alpha, X, ldx, Y, ldy):
+        self._count('axpy')
+        dt = np.dtype(_DT[code])
+        a = _flat(alpha, np.float64, 2)
+        al = complex(a[0], a[1]) if dt.kind == 'c' else a[0]
+        y = _block(Y, code, n, m, ldy)
+        y[:, :] = ops.axpy(y, _block(X, code, n, m, ldx), dt.type(al))
+        return 0
+
+    def rlh_axpy_cols(self, code, n, m, s, X, ldx, Y, ldy):
+        self._count('axpy_cols')
+        sv = _flat(s, _DT[code], m)
+        y = _block(Y, code, n, m, ldy)
+        y[:, :] = ops.axpy_cols(y, _block(X, code, n, m, ldx), sv)
+        return 0
+
+    def rlh_copy(self, code, n, m, X, ldx, Y, ldy):
+        self._count('copy')
+        _block(Y, code, n, m, ldy)[:, :] = _block(X, code, n, m, ldx)
+        return 0
+
+    def rlh_copy_cols(self, code, n, m, ind, Xall, ldx, Y, ldy):
+        self._count('copy_cols')
+        idx = _flat(ind, np.int64, m)
+        if m == 0:
+            return 0
+        xa = _block(Xall, code, n, int(idx.max()) + 1, ldx)
+        _block(Y, code, n, m, ldy)[:, :] = ops.copy_cols(xa, idx)
+        return 0
+
+    def rlh_scale_cols(self, code, n, m, s, mode, X, ldx):
+        self._count('scale_cols')
+        dt = np.dtype(_DT[code])
+        sv = _flat(s, np.float64, 2 * m if dt.kind == 'c' else m)
+        if dt.kind == 'c':
+            sv = sv.view(np.complex128)
+        x = _block(X, code, n, m, ldx)
+        x[:, :] = ops.scale_cols(x, sv, bool(mode))
+        return 0
+
+    def rlh_conj(self, code, n, m, X, ldx):
+        if code in (2, 3):
+            x = _block(X, code, n, m, ldx)
+            x[:, :] = x.conj()
+        return 0
+
+    def rlh_gather_rows(self, code, nidx, d_idx, m, X, ldx, Out, ldo):
+        self._count('gather_rows')
+        if nidx == 0 or m == 0:
+            return 0
+        idx = _flat(d_idx, np.int64, nidx)
+        x = _block(X, code, int(idx.max()) + 1, m, ldx)
+        _block(Out, code, nidx, m, ldo)[:, :] = x[:, idx]
+        return 0
+
+    # ---- operators
+    def rlh_csr_create(self, ph, code, n_rows, n_cols, indptr, indices, values):
+        ip = _flat(indptr, np.int64, n_rows + 1).copy()
+        nnz = int(ip[-1])
+        ix = _flat(indices, np.int32, nnz).copy()
+        va = _flat(values, _DT[code], nnz).copy()
+        if nnz and (ix.min() < 0 or ix.max() >= n_cols):
+            return self._fail('rlh_csr_create: column index out of range')
+        h = self._next_handle
+        self._next_handle += 1
+        self._csr[h] = _Csr(sp.csr_matrix((va, ix, ip), shape=(n_rows, n_cols)), code)
+        ph._obj.value = h
+        return 0
+
+    def rlh_csr_destroy(self, h):
+        self._csr.pop(_addr(h), None)
+        return 0
+
+    def rlh_csr_info(self, h, a, b, c, d):
+        return 0
+
+    def rlh_spmm(self, h, m, X, ldx, n_own, H, ldh, Y, ldy):
+        self._count('spmm')
+        c = self._csr[_addr(h)]
+        nr, ncol = c.mat.shape
+        if m == 0 or nr == 0:
+            return 0
+        x = np.zeros((m, ncol), dtype=_DT[c.code])
+        x[:, :n_own] = _block(X, c.code, n_own, m, ldx)
+        if ncol > n_own:
+            if not _addr(H):
+                return self._fail('rlh_spmm: halo block missing for columns >= n_own')
+            x[:, n_own:] = _block(H, c.code, ncol - n_own, m, ldh)
+        _block(Y, c.code, nr, m, ldy)[:, :] = (c.mat @ x.T).T
+        return 0
+
+    def rlh_dense_apply(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy):
+        self._count('dense_apply')
+        if order == 0:
+            a = _block(A, code, N, M, lda)              # rows of A, shape (M, N)
+        else:
+            a = _block(A, code, M, N, lda).T            # columns of A, transposed view (M, N)
+        nx, ny = (M, N) if transp else (N, M)
+        if ldx < nx or ldy < ny:
+            return self._fail('rlh_dense_apply: Matrix and vectors dimensions incompatible')
+        x = _block(X, code, nx, m, ldx)
+        _block(Y, code, ny, m, ldy)[:, :] = ops.dense_apply(a, x, bool(transp))
+        return 0
+
+    def rlh_timer_start(self):
+        return 0
+
+    def rlh_timer_stop(self, p):
+        p._obj.value = 0.0
+        return 0
+
+
+def install():
+    """Installs a fresh FakeLib as raleigh_amd's library; returns it."""
+    from raleigh_amd import _lib
+    fake = FakeLib()
+    _lib.set_library(fake)
+    return fake
+
+
+def uninstall():
+    from raleigh_amd import _lib
+    _lib.set_library(None)
