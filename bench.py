@@ -1,0 +1,259 @@
+"""Headline benchmark: one block-JCG INNER ITERATION of the abstract-vectors hot
+path (the Gram / dots / SpMM calls the solver issues per iteration,
+raleigh/core/solver.py:854-861,968-974,1321-1339,1360,1376-1381,1444-1447) on a
+synthetic n x m block, n = 215^3 = 9 938 375 (the "n = 10^7" roofline point of
+BASELINE.json), m = 32, fp64, A = 7-point 3-D Laplacian.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the rows
+are sharded over the ranks (strong scaling: the global problem is fixed), every
+Gram / dots carries one all-reduce, the SpMM one halo exchange.
+
+Prints ONE JSON line (rank 0).  `value` = algorithmic GB/s of the whole job:
+bytes of SURVEY 8(d) (9 Gram calls = 16 blocks, 4 self-dots = 4 blocks, one
+SpMM = nnz*12 + (n+1)*4 + 2 blocks) divided by the max-over-ranks step time,
+operands resident in HBM, every dot/dots returning its result to the host as the
+solver requires.
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+
+
+def lap3d_rows(nx, ny, nz, ax, ay, az, r0, r1):
+    """Rows [r0, r1) of the 7-point Laplacian of raleigh/examples/laplace.py:23-27 as a full
+    (both triangles) CSR block with GLOBAL column indices, built without the global matrix."""
+    import scipy.sparse as sp
+    n = nx * ny * nz
+    r = np.arange(r0, r1, dtype=np.int64)
+    ix, iy, iz = r % nx, (r // nx) % ny, r // (nx * ny)
+    cx, cy, cz = ((nx + 1.0) / ax) ** 2, ((ny + 1.0) / ay) ** 2, ((nz + 1.0) / az) ** 2
+    rows, cols, vals = [r], [r], [np.full(r.shape, 2 * (cx + cy + cz))]
+    for cond, shift, c in ((ix > 0, -1, cx), (ix < nx - 1, 1, cx), (iy > 0, -nx, cy), (iy < ny - 1, nx, cy),
+                           (iz > 0, -nx * ny, cz), (iz < nz - 1, nx * ny, cz)):
+        rows.append(r[cond]); cols.append(r[cond] + shift); vals.append(np.full(int(cond.sum()), -c))
+    rows = np.concatenate(rows) - r0
+    blk = sp.csr_matrix((np.concatenate(vals), (rows, np.concatenate(cols))), shape=(r1 - r0, n))
+    blk.sort_indices()
+    return blk
+
+
+
+class InnerIteration:
+    """The Gram / dots / SpMM sequence of one steady-state iteration (standard problem,
+    identity preconditioner, no deflation) on blocks X, AX, Y, AY, Z, AZ, W."""
+
+    def __init__(self, blocks, op):
+        self.b, self.op = blocks, op
+
+    def headline(self):
+        X, AX, Y, AY, Z, AZ, W = self.b
+        out = []
+        out.append(AX.dot(X))       # XAX   solver.py:857
+        out.append(X.dot(X))        # XBX   solver.py:859 (B = I: self-Gram)
+        out.append(W.dots(W))       # residual norms, solver.py:968-974
+        out.append(Y.dot(AZ))       # ZAY   solver.py:1326
+        out.append(Y.dot(Z))        # ZBY   solver.py:1328
+        out.append(Y.dots(Y))       # solver.py:1337
+        out.append(Z.dots(Z))       # solver.py:1338
+        out.append(Y.dot(X))        # Q = Y.dot(BX), solver.py:1360
+        out.append(Y.dots(Y))       # normalisation, solver.py:1376
+        out.append(Y.dot(X))        # XBY   solver.py:1379
+        out.append(Y.dot(Y))        # YBY   solver.py:1380 (self-Gram)
+        self.op.apply(Y, AY)        # AY = A Y, solver.py:1444
+        out.append(AY.dot(X))       # XAY   solver.py:1446
+        out.append(AY.dot(Y))       # YAY   solver.py:1447
+        return out
+
+    @staticmethod
+    def headline_bytes(n, m, es, nnz):
+        B = n * m * es
+        gram = 7 * 2 * B + 2 * B          # 7 two-operand + 2 self Grams = 16 blocks
+        dots = 4 * B
+        spmm = nnz * (es + 4) + (n + 1) * 4 + 2 * B
+        return gram + dots + spmm, {'gram': gram, 'dots': dots, 'spmm': spmm}
+
+
+def cpu_baseline(m, reps_target_s=12.0):
+    """The CPU oracle (oracle/, NumPy + the node's BLAS, SciPy SpMM) timed on a bounded sample
+    of the same workload: lap3d 100^3 (n = 10^6), m = 32, fp64."""
+    from oracle import Vectors as OV, SparseSymmetricMatrix as OS
+    from oracle.sparse import lap3d
+    N = 100
+    A = lap3d(N, N, N, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    rng = np.random.default_rng(1)
+    blocks = [OV(2 * rng.random((m, n)) - 1) for _ in range(7)]
+    it = InnerIteration(blocks, OS(A))
+    it.headline()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        it.headline()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > reps_target_s or reps >= 20:
+            break
+    nbytes, _ = InnerIteration.headline_bytes(n, m, 8, A.nnz)
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {'value': round(nbytes * reps / el / 1e9, 3), 'unit': 'GB/s', 'cores': int(threads),
+            'kind': 'port',
+            'sample': 'oracle (NumPy/BLAS + SciPy CSR) inner iteration, lap3d 100^3 (n=1e6), m=%d fp64, %d reps in %.1f s'
+                      % (m, reps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--side', type=int, default=215, help='lap3d side (n = side^3)')
+    ap.add_argument('--m', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('bench.py --gpus %d must be launched by torch.distributed.run with %d ranks'
+                         % (args.gpus, args.gpus))
+
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, ShardedSparseMatrix, partition
+        comm = Comm()
+    L = _lib.lib(local_rank)
+
+    side, m, es = args.side, args.m, 8
+    n = side ** 3
+    nnz = 7 * n - 2 * (side * side * 3)          # 7-point stencil minus the faces
+    if comm is None:
+        r0, r1 = 0, n
+    else:
+        off = partition(n, world)
+        r0, r1 = int(off[rank]), int(off[rank + 1])
+    nloc = r1 - r0
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    rng = np.random.default_rng(1 + rank)
+    host = 2 * rng.random((m, nloc)) - 1
+    if comm is None:
+        mk = lambda: Vectors(nloc, m, data_type=np.float64)
+    else:
+        mk = lambda: ShardedVectors(n, m, np.float64, comm=comm, offsets=off)
+    blocks = [mk() for _ in range(7)]
+    Vectors.fill(blocks[0], host)
+    del host
+    for i, b in enumerate(blocks[1:], 1):         # distinct random-looking blocks from device-side ops
+        blocks[0].copy(b, np.roll(np.arange(m), i))
+        b.add(blocks[0], 0.37 * i)
+    rows = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, r0, r1)
+    assert comm is not None or rows.nnz == nnz
+    if comm is None:
+        csr = CsrOperator(rows)
+
+        class Op:
+            def apply(self, x, y):
+                csr.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
+        op = Op()
+    else:
+        op = ShardedSparseMatrix.from_local_rows(rows, r0, n, comm, off)
+    del rows
+    it = InnerIteration(blocks, op)
+
+    def sync_all():
+        _lib.check(L.rlh_sync())
+        if comm is not None:
+            import torch
+            torch.cuda.synchronize()
+            comm.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        it.headline()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it.headline()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    nbytes, parts = InnerIteration.headline_bytes(n, m, es, nnz)
+    value = nbytes / (ms_per_step * 1e-3) / 1e9
+
+    # ---- roofline of the dominant kernel (two-operand Gram), HIP events on the kernels' stream
+    X, AX = blocks[0], blocks[1]
+    ms = ctypes.c_float()
+    res = ctypes.c_void_p()
+    _lib.check(L.rlh_malloc(ctypes.byref(res), m * m * es))
+    code = _lib.dtype_code(np.float64)
+    reps = 20
+    gram = lambda: L.rlh_gram(code, nloc, m, X.data_ptr(), X.ld(), m, AX.data_ptr(), AX.ld(), res, None)
+    _lib.check(gram())
+    _lib.check(L.rlh_timer_start())
+    for _ in range(reps):
+        _lib.check(gram())
+    _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
+    gram_ms = ms.value / reps
+    gram_bytes = 2 * nloc * m * es
+    achieved = gram_bytes / (gram_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'gram_traffic.json')
+    if os.path.exists(tpath) and world == 1:
+        try:
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    roofline = {'bound': 'hbm', 'kernel': 'gram_kernel<fp64, 2x2 tiles> (X.dot(Y), m=k=%d)' % m,
+                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'algorithmic_bytes_per_launch': gram_bytes, 'avg_launch_ms': round(gram_ms, 4),
+                'inner_iteration_frac': round(value / world / HBM_PEAK_GBS, 4)}
+
+    out = {'metric': 'inner-iter GB/s vs HBM roofline (Gram+dots+SpMM of one block-JCG iteration)',
+           'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+           'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': 'block-JCG inner iteration: 9 Gram + 4 dots + 1 SpMM, n=%d^3=%d rows, m=%d, '
+                                  '7-pt Laplacian nnz=%d, rows sharded over %d GPU(s)' % (side, n, m, nnz, world),
+                      'n': n, 'm': m, 'nnz': nnz, 'algorithmic_bytes_per_step': nbytes,
+                      'bytes_breakdown': parts},
+           'roofline': roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(m)
+    if rank == 0:
+        print(json.dumps(out))
+    if comm is not None:
+        comm.dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

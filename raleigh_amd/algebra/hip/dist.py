@@ -1,0 +1,324 @@
+"""Row-sharding of the vector blocks over the GPUs of one node.
+
+New relative to the reference, which has no distributed layer at all
+(SURVEY 2.1): one process per GPU (``torch.distributed``, backend "nccl" = RCCL
+over xGMI), GPU p owns rows [off[p], off[p+1]) of every block.
+
+* ``multiply / add / copy / scale`` are local (coefficients are replicated);
+* ``dot / dots`` = local partial + ONE all-reduce(sum) of the m x k (or m)
+  scalars, issued on the stream the kernels run on;
+* the sparse operator is row-sharded with the same partition and needs one
+  exchange step per application: the rows of X referenced by off-shard column
+  indices (send/receive lists fixed at construction).
+
+torch is plumbing here (process group, communication buffers); all arithmetic
+stays in librlhip.so.  With the "gloo" backend the same code runs on host
+buffers, which is how the CPU test tier covers it (world_size 2).
+"""
+
+import numpy as np
+import scipy.sparse as scs
+
+from ... import _lib
+from .vectors import Vectors
+from .memory import upload, download
+from .sparse import CsrOperator, full_from_upper
+
+_REAL = {np.float32: np.float32, np.float64: np.float64,
+         np.complex64: np.float32, np.complex128: np.float64}
+
+
+class Comm:
+    """Process group + communication buffers of one rank."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.on_device = (dist.get_backend(group) == 'nccl')
+        if self.on_device:
+            dev = _lib.default_device()
+            torch.cuda.set_device(dev)
+            L = _lib.lib(dev)
+            # kernels and RCCL collectives are ordered on torch's current stream
+            _lib.check(L.rlh_set_stream(torch.cuda.current_stream().cuda_stream))
+            self.device = torch.device('cuda', dev)
+        else:
+            self.device = torch.device('cpu')
+        self._red = None
+
+    def buffer(self, nbytes):
+        """A communication buffer (device memory under RCCL, host memory under gloo)."""
+        return self.torch.empty(max(int(nbytes), 1), dtype=self.torch.uint8, device=self.device)
+
+    def reduction_buffer(self, nbytes):
+        if self._red is None or self._red.numel() < nbytes:
+            self._red = self.buffer(max(nbytes, 1 << 16))
+        return self._red
+
+    def allreduce_from_device(self, buf, np_dtype, count):
+        """Sums `count` elements of dtype np_dtype held in `buf` over the ranks and
+        returns them as a host array."""
+        real = np.dtype(_REAL[np.dtype(np_dtype).type])
+        nreal = count * (2 if np.dtype(np_dtype).kind == 'c' else 1)
+        tdt = self.torch.float32 if real == np.float32 else self.torch.float64
+        view = buf[:nreal * real.itemsize].view(tdt)
+        self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
+        host = view.cpu().numpy() if self.on_device else view.numpy().copy()
+        return host.view(np_dtype)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+def partition(n, size):
+    """Row offsets of a balanced contiguous partition, rounded to 64 rows so that
+    every shard starts on a wavefront / cache-line boundary."""
+    per = -(-n // size)
+    per = -(-per // 64) * 64
+    off = [min(p * per, n) for p in range(size + 1)]
+    off[size] = n
+    return np.array(off, dtype=np.int64)
+
+
+class ShardedVectors(Vectors):
+    """Vectors whose rows are distributed over the ranks of `comm`."""
+
+    def __init__(self, arg, nvec=0, data_type=None, shallow=False, comm=None, offsets=None):
+        if isinstance(arg, ShardedVectors):
+            comm, offsets, gdim = arg._comm, arg._offsets, arg._gdim
+            super().__init__(arg, shallow=shallow)
+        elif isinstance(arg, np.ndarray):          # a GLOBAL (nvec, n) array, same on every rank
+            if comm is None:
+                raise ValueError('ShardedVectors needs a communicator')
+            gdim = arg.shape[1]
+            offsets = partition(gdim, comm.size) if offsets is None else offsets
+            r0, r1 = offsets[comm.rank], offsets[comm.rank + 1]
+            super().__init__(np.ascontiguousarray(arg[:, r0:r1]))
+        else:
+            if comm is None:
+                raise ValueError('ShardedVectors needs a communicator')
+            gdim = int(arg)
+            offsets = partition(gdim, comm.size) if offsets is None else offsets
+            nloc = int(offsets[comm.rank + 1] - offsets[comm.rank])
+            super().__init__(nloc, nvec, data_type)
+        self._comm, self._offsets, self._gdim = comm, offsets, gdim
+
+    # ---- global views
+    def dimension(self):
+        return self._gdim
+
+    def local_dimension(self):
+        return self._vdim
+
+    def comm(self):
+        return self._comm
+
+    def offsets(self):
+        return self._offsets
+
+    def new_vectors(self, arg=0, dim=None):
+        if isinstance(arg, np.ndarray):
+            return ShardedVectors(arg, comm=self._comm)
+        if dim is not None and dim != self._gdim:
+            return ShardedVectors(dim, int(arg), self.data_type(), comm=self._comm)
+        return ShardedVectors(self._gdim, int(arg), self.data_type(), comm=self._comm,
+                              offsets=self._offsets)
+
+    def clone(self):
+        return ShardedVectors(self)
+
+    def reference(self):
+        return ShardedVectors(self, shallow=True)
+
+    def fill_random(self):
+        # every rank draws the same global stream (one vector at a time) and keeps its rows:
+        # the start vectors do not depend on the number of GPUs
+        f, m = self.selected()
+        r0, r1 = self._offsets[self._comm.rank], self._offsets[self._comm.rank + 1]
+        for i in range(m):
+            row = np.random.rand(1, self._gdim)[:, r0:r1].astype(self.data_type())
+            row *= 2
+            row -= 1
+            upload(self._ptr(f + i), self._ld * self._es, row)
+
+    def fill(self, data):
+        if isinstance(data, np.ndarray) and data.shape[1] == self._gdim and self._gdim != self._vdim:
+            r0, r1 = self._offsets[self._comm.rank], self._offsets[self._comm.rank + 1]
+            data = np.ascontiguousarray(data[:, r0:r1])
+        super().fill(data)
+
+    def local_data(self):
+        return Vectors.data(self)
+
+    def data(self, i=None):
+        """GLOBAL host copy (nvec, n), assembled on every rank."""
+        loc = Vectors.data(self, i)
+        if i is not None:
+            loc = loc.reshape(1, -1)
+        c = self._comm
+        m = loc.shape[0]
+        out = np.zeros((m, self._gdim), dtype=self.data_type())
+        tt = c.torch
+        maxloc = int(np.max(np.diff(self._offsets)))
+        send = np.zeros((m, maxloc), dtype=self.data_type())
+        send[:, :loc.shape[1]] = loc
+        st = tt.from_numpy(send.view(_REAL[self.data_type()]))
+        if c.on_device:
+            st = st.to(c.device)
+        parts = [tt.empty_like(st) for _ in range(c.size)]
+        c.dist.all_gather(parts, st, group=c.group)
+        for p in range(c.size):
+            r0, r1 = self._offsets[p], self._offsets[p + 1]
+            arr = parts[p].cpu().numpy().view(self.data_type())
+            out[:, r0:r1] = arr[:, :r1 - r0]
+        return out[0] if i is not None else out
+
+    # ---- reductions: local partial + one all-reduce
+    def dot(self, other):
+        m, k = self.nvec(), other.nvec()
+        q = np.zeros((k, m), dtype=self.data_type())
+        if m == 0 or k == 0:
+            return q
+        c = self._comm
+        buf = c.reduction_buffer(m * k * self._es)
+        _lib.check(_lib.lib().rlh_gram(self._code, self._vdim, m, self._ptr(), self._ld, k,
+                                       other._ptr(), other._ld, buf.data_ptr(), None))
+        return c.allreduce_from_device(buf, self.data_type(), m * k).reshape(k, m).copy()
+
+    def dots(self, other, transp=False):
+        if transp:
+            raise NotImplementedError('transposed dots of row-sharded vectors')
+        m = self.nvec()
+        if m == 0:
+            return np.zeros((0,), dtype=self.data_type())
+        c = self._comm
+        buf = c.reduction_buffer(m * self._es)
+        _lib.check(_lib.lib().rlh_dots(self._code, self._vdim, m, self._ptr(), self._ld,
+                                       other._ptr(), other._ld, buf.data_ptr(), None))
+        return c.allreduce_from_device(buf, self.data_type(), m).copy()
+
+
+class ShardedSparseMatrix:
+    """Row-sharded symmetric/Hermitian operator with a halo exchange per application.
+
+    Every rank passes the same global SciPy matrix (upper triangle significant,
+    as in raleigh/algebra/sparse_mkl.py:18-31) or, to avoid holding it everywhere,
+    its own row block via ``local_rows=(csr_block, row0)``."""
+
+    def __init__(self, matrix, comm, offsets=None):
+        full = full_from_upper(matrix)
+        n = full.shape[0]
+        off = partition(n, comm.size) if offsets is None else offsets
+        r0, r1 = int(off[comm.rank]), int(off[comm.rank + 1])
+        self._setup(scs.csr_matrix(full[r0:r1, :]), r0, n, comm, off, int(full.nnz))
+
+    @classmethod
+    def from_local_rows(cls, rows, row0, n, comm, offsets):
+        """From this rank's rows [row0, row0 + rows.shape[0]) of the FULL (both triangles)
+        matrix with global column indices; nothing global is materialised."""
+        self = cls.__new__(cls)
+        rows = scs.csr_matrix(rows)
+        assert rows.shape[1] == n and row0 == int(offsets[comm.rank])
+        t = comm.torch.tensor([rows.nnz], dtype=comm.torch.int64, device=comm.device)
+        comm.dist.all_reduce(t, group=comm.group)
+        self._setup(rows, row0, n, comm, offsets, int(t.item()))
+        return self
+
+    def _setup(self, loc, r0, n, comm, off, nnz_global):
+        self._comm = comm
+        self._n = n
+        self._dtype = loc.data.dtype.type
+        self._offsets = off
+        r1 = r0 + loc.shape[0]
+        assert r1 == int(off[comm.rank + 1])
+        loc.sort_indices()
+        cols = loc.indices.astype(np.int64)
+        own = (cols >= r0) & (cols < r1)
+        halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
+        owner = np.searchsorted(off, halo_cols, side='right') - 1
+        new_idx = np.empty_like(cols)
+        new_idx[own] = cols[own] - r0
+        new_idx[~own] = (r1 - r0) + np.searchsorted(halo_cols, cols[~own])
+        ext = scs.csr_matrix((loc.data, new_idx.astype(np.int32), loc.indptr),
+                             shape=(r1 - r0, (r1 - r0) + halo_cols.size))
+        self._n_own = r1 - r0
+        self._n_halo = int(halo_cols.size)
+        self._op = CsrOperator(ext, n_own=self._n_own)
+        self._nnz = nnz_global
+        # receive plan: contiguous runs of halo rows per owner
+        self._recv = []                                       # (peer, halo_start, count)
+        for p in range(comm.size):
+            idx = np.nonzero(owner == p)[0]
+            if idx.size:
+                self._recv.append((p, int(idx[0]), int(idx.size)))
+        # tell every owner which of its rows this rank needs
+        wants = [None] * comm.size
+        mine = {p: (halo_cols[s:s + c] - off[p]).astype(np.int64) for p, s, c in self._recv}
+        comm.dist.all_gather_object(wants, mine, group=comm.group)
+        self._send = []                                       # (peer, device index list, count)
+        for p in range(comm.size):
+            if p != comm.rank and wants[p] and comm.rank in wants[p]:
+                idx = np.ascontiguousarray(wants[p][comm.rank])
+                dbuf = comm.buffer(idx.nbytes)
+                dbuf.copy_(comm.torch.from_numpy(idx.view(np.uint8)))
+                self._send.append((p, dbuf, int(idx.size)))
+        self._bufs = {}
+
+    def size(self):
+        return self._n
+
+    def data_type(self):
+        return np.dtype(self._dtype)
+
+    def nnz_full(self):
+        return self._nnz
+
+    def halo_rows(self):
+        return self._n_halo
+
+    def _buffers(self, m, es):
+        key = (m, es)
+        if key not in self._bufs:
+            c = self._comm
+            ns = sum(cnt for _, _, cnt in self._send)
+            nr = self._n_halo
+            self._bufs[key] = (c.buffer(ns * m * es), c.buffer(nr * m * es), c.buffer(nr * m * es))
+        return self._bufs[key]
+
+    def apply(self, x, y):
+        c, L = self._comm, _lib.lib()
+        m = x.nvec()
+        if m != y.nvec():
+            raise ValueError('Numbers of input and output vectors differ')
+        if x.dimension() != self._n or y.dimension() != self._n:
+            raise ValueError('Matrix and vectors dimensions incompatible')
+        code, es = x._code, x._es
+        halo_ptr, ldh = None, 0
+        if self._n_halo > 0 or self._send:
+            sendbuf, recvbuf, halo = self._buffers(m, es)
+            ops, soff, roff = [], 0, 0
+            tt = c.torch
+            for p, didx, cnt in self._send:                   # pack the rows each peer needs
+                _lib.check(L.rlh_gather_rows(code, cnt, didx.data_ptr(), m, x.data_ptr(), x.ld(),
+                                             sendbuf.data_ptr() + soff, cnt))
+                ops.append(c.dist.P2POp(c.dist.isend, sendbuf[soff:soff + cnt * m * es], p, group=c.group))
+                soff += cnt * m * es
+            for p, hs, cnt in self._recv:
+                ops.append(c.dist.P2POp(c.dist.irecv, recvbuf[roff:roff + cnt * m * es], p, group=c.group))
+                roff += cnt * m * es
+            if ops:
+                for w in c.dist.batch_isend_irecv(ops):
+                    w.wait()
+            roff = 0
+            for p, hs, cnt in self._recv:                     # peer blocks (ld = cnt) -> one halo block (ld = n_halo)
+                _lib.check(L.rlh_copy2d(halo.data_ptr() + hs * es, self._n_halo * es,
+                                        recvbuf.data_ptr() + roff, cnt * es, cnt * es, m, 2))
+                roff += cnt * m * es
+            if self._n_halo > 0:
+                halo_ptr, ldh = halo.data_ptr(), self._n_halo
+        self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh)

@@ -178,7 +178,7 @@ class Vectors:
     def fill_random(self):
         # host RNG then H2D, as the reference does (dense_cublas.py:119-131), so that
         # numpy.random.seed(...) gives the same start vectors on every backend
-        m, n = self.nvec(), self.dimension()
+        m, n = self.nvec(), self._vdim
         if m < 1:
             return
         data = np.random.rand(m, n).astype(self.data_type())
@@ -215,7 +215,7 @@ class Vectors:
 
     def dots(self, other, transp=False):
         L = _lib.lib()
-        m, n = self.nvec(), self.dimension()
+        m, n = self.nvec(), self._vdim
         if transp:
             w = np.zeros((n,), dtype=self.data_type())
             if n > 0:
@@ -234,7 +234,7 @@ class Vectors:
         m, k = self.nvec(), other.nvec()
         q = np.zeros((k, m), dtype=self.data_type())
         if m > 0 and k > 0:
-            _lib.check(_lib.lib().rlh_gram(self._code, self.dimension(), m, self._ptr(), self._ld,
+            _lib.check(_lib.lib().rlh_gram(self._code, self._vdim, m, self._ptr(), self._ld,
                                            k, other._ptr(), other._ld, None, _lib.host_ptr(q)))
         return q
 
@@ -318,7 +318,7 @@ class Vectors:
 
     def data(self, i=None):
         """Host COPY of the selected vectors, shape (nvec, dim) (dense_cublas.py:620-629)."""
-        m, n = self.nvec(), self.dimension()
+        m, n = self.nvec(), self._vdim
         if i is not None:
             v = np.ndarray((1, n), dtype=self._dtype)
             download(v, self._ptr(self._sel[0] + i), self._ld * self._es)

@@ -1,0 +1,92 @@
+"""Worker of tests/test_dist_gloo.py: launched by torch.distributed.run with the
+gloo backend (CPU); installs tests/fake_lib.py as the C-ABI library and checks
+the row-sharded Vectors / sparse operator against the oracle on global data."""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    import torch.distributed as dist
+    dist.init_process_group('gloo')
+    import fake_lib
+    fake_lib.install()
+    from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, ShardedSparseMatrix, partition
+    from oracle import ops
+    from oracle.sparse import lap3d
+    comm = Comm()
+    rank, size = comm.rank, comm.size
+    assert size == int(os.environ['WORLD_SIZE'])
+    off = partition(1000, size)
+    assert off[0] == 0 and off[-1] == 1000 and np.all(np.diff(off) >= 0)
+
+    for key, dt in (('d', np.float64), ('z', np.complex128), ('s', np.float32)):
+        rng = np.random.default_rng(3)         # same global data on every rank
+        n, m, k = 1003, 6, 4
+        x = rng.standard_normal((m, n)).astype(dt)
+        y = rng.standard_normal((k, n)).astype(dt)
+        if key == 'z':
+            x = x + 1j * rng.standard_normal((m, n))
+            y = y - 2j * rng.standard_normal((k, n))
+        tol = 1e-5 if key == 's' else 1e-13
+        X, Y = ShardedVectors(x, comm=comm), ShardedVectors(y, comm=comm)
+        assert X.dimension() == n and X.local_dimension() == off_len(n, size, rank)
+        g = X.dot(Y)
+        assert g.shape == (k, m)
+        assert np.linalg.norm(g - ops.gram(x, y)) < tol * np.linalg.norm(g)
+        X.select(3, 2)
+        d = X.dots(X)
+        assert np.linalg.norm(d - ops.dots(x[2:5], x[2:5])) < tol * np.linalg.norm(d)
+        X.select(m)
+        assert np.array_equal(X.data(), x)
+        q = rng.standard_normal((m, k)).astype(dt)
+        W = Y.new_vectors(k)
+        X.multiply(q, W)
+        W.add(Y, -0.5)
+        ref = ops.axpy(ops.multiply(x, q), y, -0.5)
+        assert np.linalg.norm(W.data() - ref) < 10 * tol * np.linalg.norm(ref)
+        # the random start block does not depend on the number of ranks
+        np.random.seed(11)
+        R = X.new_vectors(3)
+        R.fill_random()
+        np.random.seed(11)
+        expect = (2 * np.random.rand(3, n) - 1).astype(dt)
+        assert np.linalg.norm(R.data() - expect) < 1e-6 * np.linalg.norm(expect)
+        c = X.clone()
+        assert isinstance(c, ShardedVectors) and np.array_equal(c.data(), x)
+
+    # row-sharded sparse operator with halo exchange: stencil, and an unstructured pattern
+    A = lap3d(7, 6, 11, 1.0, 1.01, 1.02)
+    R = sp.random(A.shape[0], A.shape[0], density=0.02, random_state=5, format='csr')
+    for mat in (A, sp.csr_matrix(A + R + R.T)):
+        n = mat.shape[0]
+        rng = np.random.default_rng(9)
+        x = rng.standard_normal((5, n))
+        op = ShardedSparseMatrix(mat, comm)
+        X = ShardedVectors(x, comm=comm, offsets=op._offsets)
+        Y = X.new_vectors(5)
+        op.apply(X, Y)
+        ref = ops.csr_sym_apply(sp.triu(mat, format='csr'), x)
+        assert np.linalg.norm(Y.data() - ref) < 1e-13 * np.linalg.norm(ref)
+        if size > 1:
+            assert op.halo_rows() > 0
+    dist.barrier()
+    if rank == 0:
+        print('DIST_OK world=%d' % size)
+    dist.destroy_process_group()
+
+
+def off_len(n, size, rank):
+    from raleigh_amd.algebra.hip.dist import partition
+    off = partition(n, size)
+    return int(off[rank + 1] - off[rank])
+
+
+if __name__ == '__main__':
+    main()
