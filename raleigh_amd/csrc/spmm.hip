@@ -12,6 +12,8 @@
 // FE matrices neighbouring rows reference neighbouring columns, so these gathers
 // are coalesced across the wave and re-use lines through L2 / Infinity Cache.
 // The kernel is HBM-bound: nnz*(s+4) matrix bytes + one read of X + one write of Y.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -29,61 +31,141 @@ struct rlh_csr {
 
 namespace rlh {
 
-template <typename T, int JT>
+__device__ __forceinline__ float nt_load(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double nt_load(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ c32 nt_load(const c32 *p) {
+  return c32{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
+}
+__device__ __forceinline__ c64 nt_load(const c64 *p) {
+  return c64{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
+}
+__device__ __forceinline__ void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store(double *p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store(c32 *p, c32 v) {
+  __builtin_nontemporal_store(v.re, &p->re);
+  __builtin_nontemporal_store(v.im, &p->im);
+}
+__device__ __forceinline__ void nt_store(c64 *p, c64 v) {
+  __builtin_nontemporal_store(v.re, &p->re);
+  __builtin_nontemporal_store(v.im, &p->im);
+}
+
+// Work mapping (speed only; any placement gives the same result).  Workgroups b and b + 8
+// share an XCD and its 4 MiB L2 under the observed round-robin placement.
+//  * The slices are cut into chunks of `chunk` consecutive slices; chunk c belongs to XCD
+//    c % 8 and the workgroups of an XCD walk its chunks in order, so rows that reference each
+//    other are processed at about the same time on the same L2, and the eight XCDs advance
+//    through adjacent chunks (one contiguous window of X for the Infinity Cache).
+//  * The m vectors are cut into tiles of JT.  The waves of a workgroup take DIFFERENT tiles of
+//    the SAME slice (tiles_per_block of them), which keeps the set of rows in flight per XCD --
+//    and with it the L2 footprint of the gathered X lines -- small; the matrix entries of the
+//    slice are fetched once per workgroup through L1.
+template <typename T, int JT, int TT>
 __global__ __launch_bounds__(256) void sell_spmm_kernel(const int64_t *__restrict__ slice_ptr,
                                                         const int32_t *__restrict__ cols,
                                                         const T *__restrict__ vals, int64_t n_rows,
                                                         int64_t n_slices, const T *__restrict__ X, int64_t ldx,
                                                         int64_t n_own, const T *__restrict__ H, int64_t ldh,
-                                                        T *__restrict__ Y, int64_t ldy, int m) {
+                                                        T *__restrict__ Y, int64_t ldy, int m, int chunk,
+                                                        int ntiles, int tiles_per_block) {
   const int lane = threadIdx.x & 63;
-  const int j0 = blockIdx.y * JT;
-  const int jv = (m - j0) < JT ? (m - j0) : JT;
-  const T *__restrict__ Xp = X + (int64_t)j0 * ldx;
-  const T *__restrict__ Hp = H ? H + (int64_t)j0 * ldh : nullptr;
-  T *__restrict__ Yp = Y + (int64_t)j0 * ldy;
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t slice = wave0; slice < n_slices; slice += nwaves) {
-    const int64_t base = slice_ptr[slice];
-    const int width = (int)((slice_ptr[slice + 1] - base) >> 6);
-    const int64_t row = slice * 64 + lane;
-    T acc[JT];
+  const int wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7;                                  // gridDim.x is a multiple of 8
+  const int slices_per_block = 4 / tiles_per_block;
+  const int64_t q0 = (int64_t)(blockIdx.x >> 3) * slices_per_block + wave / tiles_per_block;
+  const int64_t q_stride = (int64_t)(gridDim.x >> 3) * slices_per_block;
+  const int64_t nchunks = (n_slices + chunk - 1) / chunk;
+  for (int tile = wave % tiles_per_block; tile < ntiles; tile += tiles_per_block) {
+    const int j0 = tile * JT;
+    const int jv = (m - j0) < JT ? (m - j0) : JT;
+    const T *__restrict__ Xp = X + (int64_t)j0 * ldx;
+    const T *__restrict__ Hp = H ? H + (int64_t)j0 * ldh : nullptr;
+    T *__restrict__ Yp = Y + (int64_t)j0 * ldy;
+    for (int64_t q = q0;; q += q_stride) {
+      const int64_t c = (q / chunk) * 8 + xcd;
+      if (c >= nchunks) break;
+      const int64_t slice = c * chunk + q % chunk;
+      if (slice >= n_slices) continue;
+      const int64_t base = slice_ptr[slice];
+      const int width = (int)((slice_ptr[slice + 1] - base) >> 6);
+      const int64_t row = slice * 64 + lane;
+      T acc[JT];
 #pragma unroll
-    for (int j = 0; j < JT; ++j) acc[j] = zero_of(T{});
-    for (int t = 0; t < width; ++t) {
-      const int64_t e = base + (int64_t)t * 64 + lane;
-      const int64_t c = cols[e];
-      const T v = vals[e];
-      const bool own = c < n_own;                    // off-shard rows live in the halo block
-      const T *xc = own ? Xp + c : Hp + (c - n_own);
-      const int64_t ldc = own ? ldx : ldh;
+      for (int j = 0; j < JT; ++j) acc[j] = zero_of(T{});
+      // entries in groups of TT: the group's column indices and values stay in registers while
+      // the vectors of the tile are walked, so the TT gathers of one vector (neighbouring
+      // entries of X for a stencil row) are issued back to back and share L1 lines
+      for (int t0 = 0; t0 < width; t0 += TT) {
+        const T *xc[TT];
+        int64_t ldc[TT];
+        T v[TT];
 #pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        const int jj = j < jv ? j : 0;               // clamp: columns >= m re-read column j0
-        fma_acc(acc[j], v, xc[(int64_t)jj * ldc]);
+        for (int u = 0; u < TT; ++u) {
+          const int t = (t0 + u) < width ? (t0 + u) : (width - 1);
+          const int64_t e = base + (int64_t)t * 64 + lane;
+          const int64_t cidx = __builtin_nontemporal_load(cols + e);   // streamed once per sweep
+          v[u] = nt_load(vals + e);
+          if (t0 + u >= width) v[u] = zero_of(T{});
+          const bool own = cidx < n_own;               // off-shard rows live in the halo block
+          xc[u] = own ? Xp + cidx : Hp + (cidx - n_own);
+          ldc[u] = own ? ldx : ldh;
+        }
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const int jj = j < jv ? j : 0;               // clamp: columns >= m re-read column j0
+#pragma unroll
+          for (int u = 0; u < TT; ++u) fma_acc(acc[j], v[u], xc[u][(int64_t)jj * ldc[u]]);
+        }
+      }
+      if (row < n_rows) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+          if (j < jv) nt_store(Yp + row + (int64_t)j * ldy, acc[j]);
       }
     }
-    if (row < n_rows) {
-#pragma unroll
-      for (int j = 0; j < JT; ++j)
-        if (j < jv) Yp[row + (int64_t)j * ldy] = acc[j];
-    }
   }
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+template <typename T, int JT, int TT>
+static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
+                       T *Y, int64_t ldy) {
+  Context &c = ctx();
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sell_spmm_kernel<T, JT, TT>, 256, 0) != hipSuccess || nb < 1)
+      nb = 1;
+    per_cu = nb > 8 ? 8 : nb;
+  }
+  static const int chunk = env_int("RLH_SPMM_CHUNK", 64);      // slices per row chunk (tunable)
+  static const int tpb_cap = env_int("RLH_SPMM_TPB", 1);       // waves of a workgroup on one slice (tunable)
+  const int ntiles = (int)((m + JT - 1) / JT);
+  int tiles_per_block = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
+  if (tiles_per_block > tpb_cap) tiles_per_block = tpb_cap >= 2 ? 2 : 1;
+  const int slices_per_block = 4 / tiles_per_block;
+  int64_t nb = (int64_t)c.num_cu * per_cu;
+  const int64_t need = ((h->n_slices + slices_per_block - 1) / slices_per_block + 7) / 8 * 8;
+  if (nb > need) nb = need;
+  nb = (nb + 7) / 8 * 8;
+  hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr, h->cols,
+                     (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                     chunk < 1 ? 1 : chunk, ntiles, tiles_per_block);
+  RLH_HIP(hipGetLastError());
+  return 0;
 }
 
 template <typename T, int JT>
 static int launch_spmm(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
                        T *Y, int64_t ldy) {
-  Context &c = ctx();
-  int64_t nb = (h->n_slices + 3) / 4;
-  const int64_t cap = (int64_t)c.num_cu * 8;
-  if (nb > cap) nb = cap;
-  dim3 grid((unsigned)nb, (unsigned)((m + JT - 1) / JT));
-  hipLaunchKernelGGL((sell_spmm_kernel<T, JT>), grid, dim3(256), 0, c.stream, h->slice_ptr, h->cols,
-                     (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m);
-  RLH_HIP(hipGetLastError());
-  return 0;
+  static const int tt = env_int("RLH_SPMM_TT", 1);             // entries per register group (tunable)
+  if (tt >= 8) return launch_spmm_t<T, JT, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  if (tt >= 4) return launch_spmm_t<T, JT, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  return launch_spmm_t<T, JT, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
 }
 
 template <int DT>
@@ -93,9 +175,10 @@ static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, i
   constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
   const T *X = (const T *)X_, *H = (const T *)H_;
   T *Y = (T *)Y_;
-  if (m <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  if (m <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  if (m <= 16 || JTMAX == 16) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  static const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
+  if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  if (m <= 16 || JTMAX == 16 || jt_cap <= 16) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
   return launch_spmm<T, (JTMAX == 32 ? 32 : 16)>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
 }
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--dtype', default='d')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--lap', type=int, default=0, help='lap3d side N (n = N^3) for the SpMM line')
+    ap.add_argument('--only', default='')
     args = ap.parse_args()
     from raleigh_amd import _lib
     from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
@@ -71,6 +72,8 @@ def main():
     ]
     print('n=%d m=%d dtype=%s block=%.3f GB' % (n, m, args.dtype, B / 1e9))
     for name, nbytes, fn in ops:
+        if args.only and args.only not in name:
+            continue
         med, mn = timed(fn)
         print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % (name, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
     if args.lap and args.dtype in 'd':
@@ -82,6 +85,8 @@ def main():
         nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
         med, mn = timed(lambda: op.apply(X, W))
         print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % ('spmm lap3d', med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
+    if args.only:
+        return
     # host-visible latency of a synchronising Gram
     t0 = time.perf_counter()
     for _ in range(20):
