@@ -1,0 +1,96 @@
+"""Host-side operators adjacent to the hot path.
+
+The reference's shift-invert operator (PARDISO, raleigh/algebra/sparse_mkl.py:51-119)
+and ILUT preconditioner (sparse_mkl.py:122-140) are MKL host factorisations.  Their
+device counterparts are "next" rows of the scope table; until they land, these
+wrappers run SciPy's SuperLU / ILU on the HOST and move the n x m block across PCIe
+twice per application.  They are NOT part of the hot path and never stand in for a
+HIP kernel: every Vectors operation still runs in librlhip.so.
+"""
+
+import numpy as np
+import scipy.sparse as scs
+import scipy.sparse.linalg as sla
+
+
+class HostOperator:
+    """Adapts a host operator ``f(x_host (m, n)) -> y_host (m, n)`` (or an object with
+    ``apply(x_host, y_host)``, the reference's preconditioner protocol,
+    raleigh/interfaces/partial_hevp.py:41-49) to device Vectors."""
+
+    def __init__(self, op):
+        self._op = op
+
+    def apply(self, x, y):
+        xh = x.data()
+        if hasattr(self._op, 'apply'):
+            yh = np.zeros_like(xh)
+            self._op.apply(xh, yh)
+        else:
+            yh = np.ascontiguousarray(self._op(xh), dtype=xh.dtype)
+        y.fill(yh)
+
+
+class IncompleteLU:
+    """Host ILU preconditioner (counterpart of sparse_mkl.py:122-140; SciPy spilu
+    instead of MKL dcsrilut, so iteration counts may differ from the reference's)."""
+
+    def __init__(self, matrix):
+        self._a = scs.csc_matrix(matrix)
+        self._ilu = None
+
+    def factorize(self, tol=1e-6, max_fill=1):
+        self._ilu = sla.spilu(self._a, drop_tol=tol, fill_factor=max(1.0, float(max_fill)) * 10)
+
+    def apply(self, x, y):
+        xh = x.data()
+        y.fill(np.ascontiguousarray(self._ilu.solve(xh.T).T))
+
+
+class SparseSymmetricSolver:
+    """Host LU of A - sigma B (counterpart of sparse_mkl.py:51-119 on SuperLU).
+
+    Factorises without pivoting in symmetric mode, so that the signs of diag(U)
+    give the inertia the caller needs to map `which` (partial_hevp.py:172-194)."""
+
+    def __init__(self, dtype=np.float64, pos_def=False):
+        self._dtype = dtype
+        self._lu = None
+
+    def analyse(self, a, sigma=0, b=None):
+        a = scs.csc_matrix(a)
+        if sigma != 0:
+            if b is None:
+                b = scs.identity(a.shape[0], dtype=a.dtype, format='csc')
+            a = a - sigma * b
+        self._a = scs.csc_matrix(a)
+        self._n = a.shape[0]
+        self._sigma = sigma
+
+    def factorize(self):
+        try:
+            self._lu = sla.splu(self._a, permc_spec='MMD_AT_PLUS_A', diag_pivot_thresh=0.0,
+                                options=dict(SymmetricMode=True))
+        except Exception:
+            raise RuntimeError('factorization failed (near singular matrix?)')
+
+    def solve(self, b, x):
+        bh = b.data()
+        x.fill(np.ascontiguousarray(self._lu.solve(np.ascontiguousarray(bh.T)).T, dtype=bh.dtype))
+
+    def apply(self, b, x):
+        self.solve(b, x)
+
+    def inertia(self):
+        d = np.real(self._lu.U.diagonal())
+        neg = int(np.sum(d < 0))
+        return neg, int(self._n - neg)
+
+    def size(self):
+        return self._n
+
+    def data_type(self):
+        return self._dtype
+
+    def sigma(self):
+        return self._sigma

@@ -1,0 +1,137 @@
+"""Partial eigenvalue problem solver for a sparse symmetric/Hermitian matrix on MI355X.
+
+Counterpart of raleigh/interfaces/partial_hevp.py:21-257 (same signature, return
+values and status codes) built on this repository's Vectors, sparse operator and
+block-JCG driver.  Preconditioned mode (T given) keeps every block on the device;
+shift-invert mode (T None) uses the host factorisation of algebra/hip/host_ops.py
+for the operator (A - sigma B)^-1 -- the reference uses PARDISO on the host too.
+"""
+
+import time
+
+import numpy
+
+from ..algebra.hip import Vectors, SparseSymmetricMatrix
+from ..algebra.hip.host_ops import SparseSymmetricSolver
+from ..core.solver import Problem, Solver, Options, DefaultConvergenceCriteria
+
+
+def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, verb=0, opt=None,
+                 vectors=None, operator=None):
+    '''Computes several eigenpairs of a sparse real symmetric / Hermitian problem
+    (arguments as raleigh/interfaces/partial_hevp.py:23-90).
+
+    Extra keywords (multi-GPU): `vectors` -- a factory ``f(n, data_type=)`` returning an
+    empty Vectors (e.g. row-sharded), `operator` -- a ready operator for A with
+    ``apply(x, y)``, ``size()`` and ``data_type()`` (e.g. ShardedSparseMatrix).
+
+    Returns (lmd, x, status): eigenvalues ascending, eigenvectors as columns, status as
+    in the reference (0 success, 1 iteration limit, 2 no search directions, 3/4 some
+    requested eigenvalues may not exist, <0 error).'''
+    if opt is None:
+        opt = Options()
+    if buckling and sigma >= 0:
+        raise ValueError('sigma must be negative in buckling mode')
+    make_vectors = vectors if vectors is not None else (lambda n, data_type: Vectors(n, data_type=data_type))
+    if B is not None:
+        opB = SparseSymmetricMatrix(A if buckling else B)
+    else:
+        if buckling:
+            raise RuntimeError('stress stiffness matrix missing in buckling mode')
+        opB = None
+
+    if T is None:       # shift-invert through a host factorisation
+        if isinstance(A, SparseSymmetricSolver):
+            solver = A
+            n, dtype, sigma = A.size(), A.data_type(), A.sigma()
+        else:
+            m, n = A.shape
+            if m != n:
+                raise ValueError('the matrix must be square')
+            dtype = A.data.dtype.type
+            solver = SparseSymmetricSolver(dtype=dtype)
+            if verb > -1:
+                print('setting up the linear system solver...')
+            start = time.time()
+            solver.analyse(A, sigma, B)
+            solver.factorize()
+            # estimate the factorization error on three random vectors (partial_hevp.py:126-162)
+            opA_ = SparseSymmetricMatrix(A)
+            b, x, y = (Vectors(n, 3, data_type=dtype) for _ in range(3))
+            x.fill_random()
+            opA_.apply(x, b)
+            z = x
+            if B is not None:
+                opB_ = SparseSymmetricMatrix(B)
+                opB_.apply(x, y)
+                z = y
+            s = x.dots(x)
+            if sigma != 0:
+                b.add(z, -sigma)
+            solver.solve(b, y)
+            y.add(x, -1)
+            t = y.dots(y)
+            err = numpy.amax(numpy.sqrt(abs(t / s)))
+            if err > 0.01:
+                if verb > -1:
+                    print('factorization too inaccurate: relative error > %.1e, '
+                          'consider moving shift slightly' % err)
+                return None, None, -1
+            if verb > -1:
+                print('estimated factorization error: %.1e' % err)
+                print('setup time: %.2e' % (time.time() - start))
+        neg, pos = solver.inertia()
+        if verb > -1:
+            print('positive eigenvalues: %d' % pos)
+            print('negative eigenvalues: %d' % neg)
+        if type(which) is tuple:
+            if len(which) != 2:
+                raise ValueError('which must be either integer or tuple of 2 integers')
+            which = (min(which[0], neg), min(which[1], pos))
+        elif buckling:
+            which = (neg, 0) if which < neg else (neg, which - neg)
+        elif neg < 1:
+            which = (0, which)
+        elif pos < 1:
+            which = (which, 0)
+        eigenvectors = make_vectors(n, data_type=dtype)
+        evp = Problem(eigenvectors, solver) if B is None else Problem(eigenvectors, solver, opB, 'pro')
+        evp_solver = Solver(evp)
+    else:               # preconditioned iterations, everything on the device
+        if buckling:
+            raise ValueError('preconditioning for buckling problem not supported')
+        opA = operator if operator is not None else SparseSymmetricMatrix(A)
+        n = opA.size()
+        dtype = numpy.dtype(opA.data_type()).type
+        eigenvectors = make_vectors(n, data_type=dtype)
+        evp = Problem(eigenvectors, opA) if B is None else Problem(eigenvectors, opA, opB, 'gen')
+        evp_solver = Solver(evp)
+        if T is not True:          # T=True: no preconditioner (identity), blocks never leave the GPU
+            evp_solver.set_preconditioner(T)
+        sigma = None
+        if type(which) is tuple:
+            raise ValueError('which must be integer if preconditioning is used')
+        which = (which, 0)
+
+    opt.convergence_criteria = DefaultConvergenceCriteria()
+    opt.convergence_criteria.set_error_tolerance('k eigenvector error', tol)
+    opt.sigma = sigma
+    start = time.time()
+    status = evp_solver.solve(eigenvectors, opt, which=which)
+    if status < 0:
+        return None, None, status
+    solve_time = time.time() - start
+    if T is None:
+        lmd = sigma / (1 - 1 / evp_solver.eigenvalues) if buckling else sigma + 1. / evp_solver.eigenvalues
+    else:
+        lmd = evp_solver.eigenvalues
+    ind = numpy.argsort(-lmd) if buckling else numpy.argsort(lmd)
+    lmd = lmd[ind]
+    if verb > -1:
+        print('iterations: %d, solve time: %.2e' % (evp_solver.iteration, solve_time))
+    x = eigenvectors.data().T
+    if eigenvectors.nvec() > 0:
+        x = x[:, ind]
+    partial_hevp.last = {'iterations': evp_solver.iteration, 'solve_time': solve_time,
+                         'residual_norms': evp_solver.residual_norms[ind] if len(ind) else None}
+    return lmd, x, status

@@ -1,0 +1,156 @@
+"""CPU tier: this repository's block-JCG driver and partial_hevp (host logic over
+tests/fake_lib.py) against the reference's known answers (tests/golden/known_answers.json)
+and the analytic Laplacian spectrum.  Eigenvalues: 1e-10 relative (BASELINE north star)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fake_lib
+
+
+@pytest.fixture(autouse=True)
+def fake():
+    f = fake_lib.install()
+    yield f
+    fake_lib.uninstall()
+
+
+def known(golden_dir):
+    return json.load(open(os.path.join(golden_dir, 'known_answers.json')))
+
+
+def test_core_doctest_problem(golden_dir):
+    from raleigh_amd.core.solver import Options, Problem, Solver, DefaultConvergenceCriteria
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    k = known(golden_dir)['core_diag100']
+    np.random.seed(1)
+    n = 100
+    opt = Options()
+    opt.convergence_criteria = DefaultConvergenceCriteria()
+    opt.convergence_criteria.set_error_tolerance('eigenvector error', 1e-8)
+    opt.verbosity = -1
+    v = Vectors(n, data_type=np.float64)
+    solver = Solver(Problem(v, Matrix(np.diag(np.arange(1, n + 1).astype(np.float64)))))
+    assert solver.solve(v, opt, which=(6, 0)) == 0
+    assert solver.block_size == k['block_size']
+    assert np.allclose(solver.eigenvalues, k['eigenvalues'], rtol=1e-10)
+    assert abs(solver.iteration - k['iterations']) <= 0.2 * k['iterations']
+    x = v.data()
+    assert np.allclose(x @ x.T, np.eye(6), atol=1e-8)
+
+
+def test_partial_hevp_identity_preconditioner(golden_dir):
+    from raleigh_amd.interfaces import partial_hevp
+    from oracle.sparse import lap3d
+    k = known(golden_dir)['hevp_lap12_id5']
+    A = lap3d(12, 11, 10, 1.0, 1.01, 1.02)
+    np.random.seed(1)
+    from raleigh_amd.core.solver import Options
+    opt = Options()
+    opt.max_iter = 500
+    lmd, x, status = partial_hevp(A, T=True, which=5, tol=1e-8, verb=-1, opt=opt)
+    assert status == 0
+    assert np.allclose(lmd, k['eigenvalues'], rtol=1e-10)
+    r = A @ x - x * lmd
+    assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
+
+
+def test_partial_hevp_shift_invert_config1(golden_dir):
+    """BASELINE config 1: lap3d(30,30,30,1,1.01,1.02), sigma = 0, 6 eigenvalues, tol 1e-6."""
+    from raleigh_amd.interfaces import partial_hevp
+    from oracle.sparse import lap3d
+    k = known(golden_dir)['hevp_lap30_si6']
+    A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(A, sigma=0, which=6, tol=1e-6, verb=-1)
+    assert status == 0
+    assert np.allclose(lmd, k['eigenvalues'], rtol=1e-10)
+
+
+def test_partial_hevp_ilu_config3_mode(golden_dir):
+    """Preconditioned mode of config 3 on the Laplacian stand-in: 10 smallest with a host ILU."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip.host_ops import IncompleteLU
+    from oracle.sparse import lap3d
+    k = known(golden_dir)['hevp_lap30_ilu10']
+    A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
+    np.random.seed(1)
+    T = IncompleteLU(A)
+    T.factorize()
+    lmd, x, status = partial_hevp(A, T=T, which=10, tol=1e-6, verb=-1)
+    assert status == 0
+    assert np.allclose(lmd, k['eigenvalues'], rtol=1e-8)
+    r = A @ x - x * lmd
+    assert np.max(np.linalg.norm(r, axis=0)) <= 10 * max(k['residual_norms'])
+
+
+@pytest.mark.parametrize('dt', [np.complex128, np.float32])
+def test_dense_both_ends_and_largest(dt):
+    from raleigh_amd.core.solver import Options, Problem, Solver, DefaultConvergenceCriteria
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    rng = np.random.default_rng(4)
+    n = 80
+    H = rng.standard_normal((n, n))
+    if dt == np.complex128:
+        H = H + 1j * rng.standard_normal((n, n))
+    H = ((H + H.conj().T) / 2 + np.diag(np.arange(n) * 2.0)).astype(dt)
+    exact = np.linalg.eigvalsh(H.astype(np.complex128))
+    tol = 1e-9 if dt == np.complex128 else 2e-4
+    for which, expect in (((3, 2), np.concatenate((exact[:3], exact[-2:]))), (4, None)):
+        np.random.seed(1)
+        opt = Options()
+        opt.convergence_criteria = DefaultConvergenceCriteria()
+        opt.convergence_criteria.set_error_tolerance('residual', 1e-10 if dt == np.complex128 else 1e-5)
+        opt.verbosity = -1
+        opt.max_iter = 600
+        v = Vectors(n, data_type=dt)
+        solver = Solver(Problem(v, Matrix(np.ascontiguousarray(H))))
+        status = solver.solve(v, opt, which=which)
+        assert status == 0
+        got = np.sort(solver.eigenvalues)
+        if expect is None:      # `which` largest in modulus
+            expect = exact[np.argsort(-np.abs(exact))[:which]]
+            assert len(got) >= which
+            for e in expect:
+                assert np.min(np.abs(got - e)) < tol * np.abs(e)
+        else:
+            assert np.allclose(got, np.sort(expect), rtol=tol)
+
+
+def test_generalized_problem():
+    from raleigh_amd.core.solver import Options, Problem, Solver, DefaultConvergenceCriteria
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    import scipy.linalg as sla
+    rng = np.random.default_rng(6)
+    n = 70
+    A = np.diag(np.arange(1.0, n + 1))
+    C = rng.standard_normal((n, n)) * 0.05
+    B = np.eye(n) * 2.0 + (C + C.T) / 2
+    exact = sla.eigh(A, B, eigvals_only=True)
+    np.random.seed(1)
+    opt = Options()
+    opt.convergence_criteria = DefaultConvergenceCriteria()
+    opt.convergence_criteria.set_error_tolerance('kinematic eigenvector error', 1e-8)
+    opt.verbosity = -1
+    opt.max_iter = 600
+    v = Vectors(n, data_type=np.float64)
+    solver = Solver(Problem(v, Matrix(A), Matrix(np.ascontiguousarray(B))))
+    assert solver.solve(v, opt, which=(4, 0)) == 0
+    assert np.allclose(np.sort(solver.eigenvalues), exact[:4], rtol=1e-9)
+
+
+def test_small_problem_falls_through_to_dense_rr():
+    from raleigh_amd.core.solver import Options, Problem, Solver
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    n = 12
+    np.random.seed(1)
+    A = np.diag(np.arange(1.0, n + 1))
+    opt = Options()
+    opt.verbosity = -1
+    v = Vectors(n, data_type=np.float64)
+    solver = Solver(Problem(v, Matrix(A)))
+    assert solver.solve(v, opt, which=(3, 0)) == 0
+    assert np.allclose(np.sort(solver.eigenvalues), np.arange(1.0, n + 1), rtol=1e-10)
