@@ -118,6 +118,52 @@ def cpu_baseline(m, reps_target_s=12.0):
                       % (m, reps, el)}
 
 
+def solve_ten(side, comm):
+    """Seconds to 10 eigenpairs (second half of BASELINE.json's metric): the repository's
+    block-JCG driver on lap3d(side^3), 10 smallest eigenvalues, eigenvector tolerance 1e-6, no
+    preconditioner (all blocks stay in HBM), rows sharded over the ranks; checked against the
+    analytic spectrum."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from oracle.sparse import lap3d_eigenvalues
+    n = side ** 3
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 5000
+    if comm is None:
+        from raleigh_amd.algebra.hip import CsrOperator
+
+        class Op:
+            def __init__(self):
+                self.csr = CsrOperator(lap3d_rows(side, side, side, 1.0, 1.01, 1.02, 0, n))
+
+            def size(self):
+                return n
+
+            def data_type(self):
+                return np.float64
+
+            def apply(self, x, y):
+                self.csr.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
+        op, vectors = Op(), None
+    else:
+        from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix, partition
+        off = partition(n, comm.size)
+        r0, r1 = int(off[comm.rank]), int(off[comm.rank + 1])
+        op = ShardedSparseMatrix.from_local_rows(lap3d_rows(side, side, side, 1.0, 1.01, 1.02, r0, r1),
+                                                 r0, n, comm, off)
+        vectors = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=off)
+    t0 = time.perf_counter()
+    lmd, x, status = partial_hevp(None, T=True, which=10, tol=1e-6, verb=-1, opt=opt, vectors=vectors,
+                                  operator=op)
+    seconds = time.perf_counter() - t0
+    ana = lap3d_eigenvalues(side, side, side, 1.0, 1.01, 1.02, 10)
+    err = float(np.max(np.abs(lmd[:10] - ana) / ana)) if status == 0 and len(lmd) >= 10 else None
+    return {'problem': 'lap3d %d^3 (n=%d), 10 smallest eigenpairs, tol 1e-6, no preconditioner' % (side, n),
+            'seconds': round(seconds, 3), 'status': int(status), 'iterations': int(partial_hevp.last['iterations']),
+            'max_rel_eigenvalue_error': err}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -126,6 +172,8 @@ def main():
     ap.add_argument('--side', type=int, default=215, help='lap3d side (n = side^3)')
     ap.add_argument('--m', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--solve-side', type=int, default=100,
+                    help='lap3d side of the end-to-end "seconds to 10 eigenpairs" run (0: skip)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -247,6 +295,8 @@ def main():
                       'n': n, 'm': m, 'nnz': nnz, 'algorithmic_bytes_per_step': nbytes,
                       'bytes_breakdown': parts},
            'roofline': roofline}
+    if args.solve_side > 0:
+        out['solve'] = solve_ten(args.solve_side, comm)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(m)
     if rank == 0:

@@ -76,6 +76,24 @@ def main():
         assert np.linalg.norm(Y.data() - ref) < 1e-13 * np.linalg.norm(ref)
         if size > 1:
             assert op.halo_rows() > 0
+    # the block-JCG driver on row-sharded blocks: same eigenvalues on any number of ranks
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from oracle.sparse import lap3d_eigenvalues
+    A = lap3d(10, 9, 8, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    op = ShardedSparseMatrix(A, comm)
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 800
+    mk = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=op._offsets)
+    lmd, x, status = partial_hevp(None, T=True, which=4, tol=1e-8, verb=-1, opt=opt, vectors=mk, operator=op)
+    assert status == 0, status
+    ana = lap3d_eigenvalues(10, 9, 8, 1.0, 1.01, 1.02, 4)
+    assert np.max(np.abs(lmd - ana) / ana) < 1e-10
+    assert x.shape == (n, 4)
+    r = A @ x - x * lmd
+    assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
     dist.barrier()
     if rank == 0:
         print('DIST_OK world=%d' % size)
