@@ -1,1 +1,2 @@
 from .partial_hevp import partial_hevp  # noqa: F401
+from .pca import pca, pca_error  # noqa: F401
