@@ -44,8 +44,13 @@ class Comm:
             dev = _lib.default_device()
             torch.cuda.set_device(dev)
             L = _lib.lib(dev)
-            # kernels and RCCL collectives are ordered on torch's current stream
-            _lib.check(L.rlh_set_stream(torch.cuda.current_stream().cuda_stream))
+            # One explicit (non-default) stream carries the kernels of librlhip AND is torch's
+            # current stream, so RCCL collectives / copies issued through torch are ordered
+            # with them.  (The legacy default stream has handle 0, which rlh_set_stream
+            # reads as "use the library's own stream" -- hence a dedicated stream.)
+            self.stream = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(self.stream)
+            _lib.check(L.rlh_set_stream(self.stream.cuda_stream))
             self.device = torch.device('cuda', dev)
         else:
             self.device = torch.device('cpu')

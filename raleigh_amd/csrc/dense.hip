@@ -11,6 +11,8 @@
 // each accumulator register stores as 128-byte contiguous runs of the column-major Y.
 // Other dtypes (f64, complex): generic LDS-tiled VALU kernel (parity path; the BASELINE dense
 // configurations are fp32).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rlh {
@@ -27,107 +29,106 @@ struct DenseArgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BN>
-__global__ __launch_bounds__(256) void dense_mfma_f32_kernel(DenseArgs a) {
-  constexpr int BM = 64, BK = 32, SK = BK + 1;
+// C^T tile of BN vectors x MR output rows per 256-thread workgroup, BK = 32, LDS double
+// buffered (one barrier per K step, global loads of step t+1 in flight during the MFMAs of
+// step t).  gridDim.z splits K; with more than one split the partial tiles go to a workspace
+// [split][vector][row] that dense_splitk_reduce sums in a fixed order.
+// Requires 16-byte aligned A / X with leading dimensions that are multiples of 4 floats.
+template <int MR, int BN, bool A_KC>
+__global__ __launch_bounds__(256) void dense_mfma_f32_kernel(DenseArgs a, float *__restrict__ part, int64_t kchunk) {
+  constexpr int BK = 32, SK = BK + 1;
   constexpr int WGN = (BN >= 64) ? 2 : 1;          // waves along the vector dimension
   constexpr int WGM = 4 / WGN;                     // waves along the output-row dimension
-  constexpr int TN = BN / WGN / 32;                // 32x32 tiles per wave (vectors)
-  constexpr int TM = BM / WGM / 32 > 0 ? BM / WGM / 32 : 1;
-  static_assert(BM / WGM >= 32 || WGM == 4, "tile split");
-  constexpr int MROWS = (WGM == 4) ? 128 : BM;     // BN == 32 uses a 128-row tile so 4 waves stay busy
-  constexpr int A_UNITS = MROWS * BK / 4 / 256;    // 16-byte units per thread
-  constexpr int B_UNITS = BN * BK / 4 / 256 > 0 ? BN * BK / 4 / 256 : 1;
+  constexpr int TN = BN / WGN / 32, TM = MR / WGM / 32;
+  static_assert(TN >= 1 && TM >= 1, "tile split");
+  constexpr int A_UNITS = MR * BK / 4 / 256;       // 16-byte units per thread and K step
+  constexpr int B_UNITS = BN * BK / 4 / 256;
+  static_assert(A_UNITS >= 1 && B_UNITS >= 1, "tile too small for 256 threads");
 
-  __shared__ float ldsA[MROWS * SK];
-  __shared__ float ldsB[BN * SK];
+  __shared__ float ldsA[2][MR * SK];
+  __shared__ float ldsB[2][BN * SK];
 
-  const float *A = (const float *)a.A;
-  const float *X = (const float *)a.X;
-  float *Y = (float *)a.Y;
+  const float *__restrict__ A = (const float *)a.A;
+  const float *__restrict__ X = (const float *)a.X;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int64_t i0 = (int64_t)blockIdx.x * MROWS;
+  const int64_t i0 = (int64_t)blockIdx.x * MR;
   const int v0 = blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk) < a.nx ? (kbeg + kchunk) : a.nx;
 
   float4 ra[A_UNITS], rb[B_UNITS];
 
   auto load_tiles = [&](int64_t k0) {
+    const bool tail = (k0 + BK > kend);              // wave-uniform: only the last K step masks
 #pragma unroll
     for (int q = 0; q < A_UNITS; ++q) {
       const int u = tid + q * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.a_kcontig) {           // unit = 4 consecutive k of one output row
+      float4 v;
+      if (A_KC) {                  // unit = 4 consecutive k of one output row
         const int r = u / (BK / 4), kq = (u % (BK / 4)) * 4;
-        const int64_t i = i0 + r, k = k0 + kq;
-        if (i < a.ny) {
-          const float *p = A + i * a.lda + k;
-          if (k + 3 < a.nx && ((((uintptr_t)p) & 15) == 0)) v = *(const float4 *)p;
-          else {
-            if (k + 0 < a.nx) v.x = p[0];
-            if (k + 1 < a.nx) v.y = p[1];
-            if (k + 2 < a.nx) v.z = p[2];
-            if (k + 3 < a.nx) v.w = p[3];
-          }
+        int64_t i = i0 + r;
+        i = i < a.ny ? i : a.ny - 1;                 // clamped rows are computed but never stored
+        int64_t k = k0 + kq;
+        const int64_t kc = (k + 3 < a.lda) ? k : 0;
+        v = *(const float4 *)(A + i * a.lda + kc);
+        if (tail) {
+          if (k + 0 >= kend) v.x = 0.f;
+          if (k + 1 >= kend) v.y = 0.f;
+          if (k + 2 >= kend) v.z = 0.f;
+          if (k + 3 >= kend) v.w = 0.f;
         }
       } else {                     // unit = 4 consecutive output rows at one k
-        const int kk = u / (MROWS / 4), rq = (u % (MROWS / 4)) * 4;
-        const int64_t i = i0 + rq, k = k0 + kk;
-        if (k < a.nx) {
-          const float *p = A + k * a.lda + i;
-          if (i + 3 < a.ny && ((((uintptr_t)p) & 15) == 0)) v = *(const float4 *)p;
-          else {
-            if (i + 0 < a.ny) v.x = p[0];
-            if (i + 1 < a.ny) v.y = p[1];
-            if (i + 2 < a.ny) v.z = p[2];
-            if (i + 3 < a.ny) v.w = p[3];
-          }
-        }
+        const int kk = u / (MR / 4), rq = (u % (MR / 4)) * 4;
+        int64_t i = i0 + rq;
+        i = (i + 3 < a.lda) ? i : 0;
+        const int64_t k = k0 + kk;
+        const int64_t kc = k < kend ? k : kbeg;
+        v = *(const float4 *)(A + kc * a.lda + i);
+        if (tail && k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       ra[q] = v;
     }
 #pragma unroll
     for (int q = 0; q < B_UNITS; ++q) {
       const int u = tid + q * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int c = u / (BK / 4), kq = (u % (BK / 4)) * 4;
+      int vc = v0 + c;
+      vc = vc < a.m ? vc : a.m - 1;
       const int64_t k = k0 + kq;
-      if (u < BN * BK / 4 && v0 + c < a.m) {
-        const float *p = X + (int64_t)(v0 + c) * a.ldx + k;
-        if (k + 3 < a.nx && ((((uintptr_t)p) & 15) == 0)) v = *(const float4 *)p;
-        else {
-          if (k + 0 < a.nx) v.x = p[0];
-          if (k + 1 < a.nx) v.y = p[1];
-          if (k + 2 < a.nx) v.z = p[2];
-          if (k + 3 < a.nx) v.w = p[3];
-        }
+      const int64_t kc = (k + 3 < a.ldx) ? k : 0;
+      float4 v = *(const float4 *)(X + (int64_t)vc * a.ldx + kc);
+      if (tail) {
+        if (k + 0 >= kend) v.x = 0.f;
+        if (k + 1 >= kend) v.y = 0.f;
+        if (k + 2 >= kend) v.z = 0.f;
+        if (k + 3 >= kend) v.w = 0.f;
       }
       rb[q] = v;
     }
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    float *la = ldsA[buf], *lb = ldsB[buf];
 #pragma unroll
     for (int q = 0; q < A_UNITS; ++q) {
       const int u = tid + q * 256;
-      if (a.a_kcontig) {
+      if (A_KC) {
         const int r = u / (BK / 4), kq = (u % (BK / 4)) * 4;
-        float *d = ldsA + r * SK + kq;
+        float *d = la + r * SK + kq;
         d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
       } else {
-        const int kk = u / (MROWS / 4), rq = (u % (MROWS / 4)) * 4;
-        float *d = ldsA + rq * SK + kk;
+        const int kk = u / (MR / 4), rq = (u % (MR / 4)) * 4;
+        float *d = la + rq * SK + kk;
         d[0] = ra[q].x; d[SK] = ra[q].y; d[2 * SK] = ra[q].z; d[3 * SK] = ra[q].w;
       }
     }
 #pragma unroll
     for (int q = 0; q < B_UNITS; ++q) {
       const int u = tid + q * 256;
-      if (u < BN * BK / 4) {
-        const int c = u / (BK / 4), kq = (u % (BK / 4)) * 4;
-        float *d = ldsB + c * SK + kq;
-        d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w;
-      }
+      const int c = u / (BK / 4), kq = (u % (BK / 4)) * 4;
+      float *d = lb + c * SK + kq;
+      d[0] = rb[q].x; d[1] = rb[q].y; d[2] = rb[q].z; d[3] = rb[q].w;
     }
   };
 
@@ -140,28 +141,37 @@ __global__ __launch_bounds__(256) void dense_mfma_f32_kernel(DenseArgs a) {
       for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
-  const int mrow0 = wm * (MROWS / WGM), vcol0 = wn * (BN / WGN);
-  load_tiles(0);
-  for (int64_t k0 = 0; k0 < a.nx; k0 += BK) {
-    __syncthreads();
-    store_tiles();
-    __syncthreads();
-    if (k0 + BK < a.nx) load_tiles(k0 + BK);
+  const int mrow0 = wm * (MR / WGM), vcol0 = wn * (BN / WGN);
+  int buf = 0;
+  if (kbeg < kend) {
+    load_tiles(kbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK < kend);
+    if (more) load_tiles(k0 + BK);
+    const float *la = ldsA[buf], *lb = ldsB[buf];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       float fx[TN], fa[TM];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) fx[tn] = ldsB[(vcol0 + tn * 32 + fr) * SK + 2 * ks + fk];
+      for (int tn = 0; tn < TN; ++tn) fx[tn] = lb[(vcol0 + tn * 32 + fr) * SK + 2 * ks + fk];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) fa[tm] = ldsA[(mrow0 + tm * 32 + fr) * SK + 2 * ks + fk];
+      for (int tm = 0; tm < TM; ++tm) fa[tm] = la[(mrow0 + tm * 32 + fr) * SK + 2 * ks + fk];
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fx[tn], fa[tm], acc[tn][tm], 0, 0, 0);
     }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
   // D[v][i]: col (lane & 31) = output row i, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = vector v
+  float *__restrict__ out = part ? part + (int64_t)blockIdx.z * a.m * a.ny : (float *)a.Y;
+  const int64_t ldo = part ? a.ny : a.ldy;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -170,8 +180,19 @@ __global__ __launch_bounds__(256) void dense_mfma_f32_kernel(DenseArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int v = v0 + vcol0 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int64_t i = i0 + mrow0 + tm * 32 + (lane & 31);
-        if (v < a.m && i < a.ny) Y[i + (int64_t)v * a.ldy] = acc[tn][tm][r];
+        if (v < a.m && i < a.ny) out[i + (int64_t)v * ldo] = acc[tn][tm][r];
       }
+}
+
+__global__ __launch_bounds__(256) void dense_splitk_reduce(const float *__restrict__ part, int splits, int64_t ny, int m,
+                                                           float *__restrict__ Y, int64_t ldy) {
+  const int v = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ny; i += stride) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[((int64_t)z * m + v) * ny + i];
+    Y[i + (int64_t)v * ldy] = s;
+  }
 }
 
 // Generic VALU GEMM for f64 / complex: 64 x 64 output tile, BK = 16, 4 x 4 micro-tile per thread.
@@ -236,28 +257,65 @@ __global__ __launch_bounds__(256) void dense_valu_kernel(DenseArgs a) {
     }
 }
 
+static int env_int_d(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+template <int MR, int BN>
+static int launch_mfma(const DenseArgs &a) {
+  Context &c = ctx();
+  const int64_t bx = (a.ny + MR - 1) / MR, by = (a.m + BN - 1) / BN;
+  // split K until there are a few workgroups per CU (the M x m output alone gives too few)
+  static const int target = env_int_d("RLH_DENSE_WG_PER_CU", 8);
+  int64_t splits = ((int64_t)c.num_cu * target + bx * by - 1) / (bx * by);
+  const int64_t max_by_k = (a.nx + 32 * 16 - 1) / (32 * 16);           // at least 16 K steps per split
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits > 16) splits = 16;
+  while (splits > 1 && (size_t)splits * a.m * a.ny * sizeof(float) > kWorkspaceBytes) --splits;
+  if (splits < 1) splits = 1;
+  int64_t kchunk = ((a.nx + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.nx + kchunk - 1) / kchunk;
+  if (splits < 1) { splits = 1; kchunk = 32; }
+  float *part = splits > 1 ? (float *)c.work : nullptr;
+  dim3 grid((unsigned)bx, (unsigned)by, (unsigned)splits);
+  if (a.a_kcontig)
+    hipLaunchKernelGGL((dense_mfma_f32_kernel<MR, BN, true>), grid, dim3(256), 0, c.stream, a, part, kchunk);
+  else
+    hipLaunchKernelGGL((dense_mfma_f32_kernel<MR, BN, false>), grid, dim3(256), 0, c.stream, a, part, kchunk);
+  RLH_HIP(hipGetLastError());
+  if (splits > 1) {
+    int64_t nb = (a.ny + 255) / 256;
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(dense_splitk_reduce, dim3((unsigned)nb, (unsigned)a.m), dim3(256), 0, c.stream, part,
+                       (int)splits, a.ny, a.m, (float *)a.Y, a.ldy);
+    RLH_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 template <int DT>
 static int dense_impl(const DenseArgs &a) {
   using T = typename DType<DT>::T;
   Context &c = ctx();
+  bool mfma_ok = false;
   if constexpr (DT == RLH_S) {
-    if (a.m > 64) {
-      dim3 grid((unsigned)((a.ny + 63) / 64), (unsigned)((a.m + 127) / 128));
-      hipLaunchKernelGGL((dense_mfma_f32_kernel<128>), grid, dim3(256), 0, c.stream, a);
-    } else if (a.m > 32) {
-      dim3 grid((unsigned)((a.ny + 63) / 64), 1);
-      hipLaunchKernelGGL((dense_mfma_f32_kernel<64>), grid, dim3(256), 0, c.stream, a);
-    } else {
-      dim3 grid((unsigned)((a.ny + 127) / 128), 1);
-      hipLaunchKernelGGL((dense_mfma_f32_kernel<32>), grid, dim3(256), 0, c.stream, a);
-    }
-  } else {
-    dim3 grid((unsigned)((a.ny + 63) / 64), (unsigned)((a.m + 63) / 64));
-    if (a.conj_a)
-      hipLaunchKernelGGL((dense_valu_kernel<T, true>), grid, dim3(256), 0, c.stream, a);
-    else
-      hipLaunchKernelGGL((dense_valu_kernel<T, false>), grid, dim3(256), 0, c.stream, a);
+    mfma_ok = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.X)) & 15u) == 0 &&
+              (a.lda % 4 == 0) && (a.ldx % 4 == 0) && a.lda >= 4 && a.ldx >= 4 && a.nx > 0;
   }
+  if constexpr (DT == RLH_S) {
+    if (mfma_ok) {
+      static const int mr = env_int_d("RLH_DENSE_MR", 128);
+      if (a.m > 64) return mr == 64 ? launch_mfma<64, 128>(a) : launch_mfma<128, 128>(a);
+      if (a.m > 32) return launch_mfma<128, 64>(a);
+      return launch_mfma<128, 32>(a);
+    }
+  }
+  dim3 grid((unsigned)((a.ny + 63) / 64), (unsigned)((a.m + 63) / 64));
+  if (a.conj_a)
+    hipLaunchKernelGGL((dense_valu_kernel<T, true>), grid, dim3(256), 0, c.stream, a);
+  else
+    hipLaunchKernelGGL((dense_valu_kernel<T, false>), grid, dim3(256), 0, c.stream, a);
   RLH_HIP(hipGetLastError());
   return 0;
 }
