@@ -172,6 +172,8 @@ def main():
     ap.add_argument('--side', type=int, default=215, help='lap3d side (n = side^3)')
     ap.add_argument('--m', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='use the sharded (torch.distributed / RCCL) code path even with one rank')
     ap.add_argument('--solve-side', type=int, default=100,
                     help='lap3d side of the end-to-end "seconds to 10 eigenpairs" run (0: skip)')
     args = ap.parse_args()
@@ -186,10 +188,12 @@ def main():
     from raleigh_amd import _lib
     from raleigh_amd.algebra.hip import Vectors, CsrOperator
     comm = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, ShardedSparseMatrix, partition
         comm = Comm()

@@ -61,7 +61,7 @@ __device__ __forceinline__ void nt_store(c64 *p, c64 v) {
 //    and with it the L2 footprint of the gathered X lines -- small; the matrix entries of the
 //    slice are fetched once per workgroup through L1.
 template <typename T, int JT, int TT>
-__global__ __launch_bounds__(256) void sell_spmm_kernel(const int64_t *__restrict__ slice_ptr,
+__global__ __launch_bounds__(256, (JT * TT >= 64 ? 1 : 2)) void sell_spmm_kernel(const int64_t *__restrict__ slice_ptr,
                                                         const int32_t *__restrict__ cols,
                                                         const T *__restrict__ vals, int64_t n_rows,
                                                         int64_t n_slices, const T *__restrict__ X, int64_t ldx,
@@ -110,12 +110,20 @@ __global__ __launch_bounds__(256) void sell_spmm_kernel(const int64_t *__restric
           xc[u] = own ? Xp + cidx : Hp + (cidx - n_own);
           ldc[u] = own ? ldx : ldh;
         }
+        // all TT x JT gathers are issued before the first FMA needs one (memory-level
+        // parallelism comes from the wave itself, not from occupancy)
+        T xv[TT][JT];
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-          const int jj = j < jv ? j : 0;               // clamp: columns >= m re-read column j0
+        for (int u = 0; u < TT; ++u)
 #pragma unroll
-          for (int u = 0; u < TT; ++u) fma_acc(acc[j], v[u], xc[u][(int64_t)jj * ldc[u]]);
-        }
+          for (int j = 0; j < JT; ++j) {
+            const int jj = j < jv ? j : 0;             // clamp: columns >= m re-read column j0
+            xv[u][j] = xc[u][(int64_t)jj * ldc[u]];
+          }
+#pragma unroll
+        for (int u = 0; u < TT; ++u)
+#pragma unroll
+          for (int j = 0; j < JT; ++j) fma_acc(acc[j], v[u], xv[u][j]);
       }
       if (row < n_rows) {
 #pragma unroll
@@ -141,6 +149,8 @@ static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, i
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sell_spmm_kernel<T, JT, TT>, 256, 0) != hipSuccess || nb < 1)
       nb = 1;
     per_cu = nb > 8 ? 8 : nb;
+    const int cap = env_int("RLH_SPMM_WG_PER_CU", 2);       // 0: as many as fit (tunable; 2 measured best)
+    if (cap > 0 && per_cu > cap) per_cu = cap;
   }
   static const int chunk = env_int("RLH_SPMM_CHUNK", 64);      // slices per row chunk (tunable)
   static const int tpb_cap = env_int("RLH_SPMM_TPB", 1);       // waves of a workgroup on one slice (tunable)
