@@ -45,6 +45,9 @@ class AMatrix:
     def dots(self):
         return self.__op.dots()
 
+    def frobenius2(self):
+        return float(numpy.sum(numpy.abs(self.__op.dots())))
+
     def data_type(self):
         return self.__op.data_type()
 

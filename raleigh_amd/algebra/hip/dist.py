@@ -327,3 +327,150 @@ class ShardedSparseMatrix:
             if self._n_halo > 0:
                 halo_ptr, ldh = halo.data_ptr(), self._n_halo
         self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh)
+
+
+class ShardedDenseMatrix:
+    """Dense operator whose ROWS are distributed over the ranks (BASELINE configs 2/4: the PCA
+    data matrix, samples sharded).  Vectors of the row dimension M are row-sharded
+    (ShardedVectors with this matrix' partition); vectors of the column dimension N are
+    REPLICATED plain Vectors (every rank holds and updates an identical copy).
+
+      apply(x, y)              y_p = A_p x            local GEMM, no communication
+      apply(z, y, transp=True) y = sum_p A_p^H z_p    local GEMM + one all-reduce of the N x k block
+
+    Same surface as Matrix (dense_cublas.py:635-776: shape/order/data_type/dots/new_vectors/apply)."""
+
+    def __init__(self, local_rows, comm, offsets=None, global_rows=None):
+        from .matrix import Matrix
+        local_rows = np.ascontiguousarray(local_rows)
+        self._comm = comm
+        self._loc = Matrix(local_rows)
+        mloc, n = local_rows.shape
+        counts = [None] * comm.size
+        comm.dist.all_gather_object(counts, int(mloc), group=comm.group)
+        off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        if offsets is not None:
+            assert np.array_equal(off, offsets), 'local row counts do not match the partition'
+        self._offsets = off
+        self._shape = (int(off[-1]), n)
+        if global_rows is not None:
+            assert global_rows == self._shape[0]
+        self._dtype = local_rows.dtype.type
+
+    @classmethod
+    def from_global(cls, a, comm):
+        """Every rank passes the same global array and keeps its row block."""
+        off = partition(a.shape[0], comm.size)
+        return cls(a[off[comm.rank]:off[comm.rank + 1], :], comm, offsets=off)
+
+    def shape(self):
+        return self._shape
+
+    def order(self):
+        return 'C_CONTIGUOUS'
+
+    def data_type(self):
+        return self._dtype
+
+    def is_complex(self):
+        return self._loc.is_complex()
+
+    def comm(self):
+        return self._comm
+
+    def offsets(self):
+        return self._offsets
+
+    def local(self):
+        return self._loc
+
+    def new_vectors(self, dim=None, nv=0):
+        m, n = self._shape
+        if dim is None:
+            dim = n
+        if dim == m and m != n:
+            return ShardedVectors(m, nv, self._dtype, comm=self._comm, offsets=self._offsets)
+        if dim == n:
+            return Vectors(n, nv, self._dtype)
+        raise ValueError('a row-sharded matrix creates vectors of its row or column dimension only')
+
+    def dots(self):
+        """Squared row norms of the LOCAL rows (use frobenius2() for the global sum)."""
+        return self._loc.dots()
+
+    def frobenius2(self):
+        loc = np.array([float(np.sum(np.abs(self._loc.dots())))], dtype=np.float64)
+        t = self._comm.torch.from_numpy(loc)
+        if self._comm.on_device:
+            t = t.to(self._comm.device)
+        self._comm.dist.all_reduce(t, group=self._comm.group)
+        return float(t.cpu().numpy()[0])
+
+    def apply(self, x, y, transp=False):
+        m, n = self._shape
+        k = x.nvec()
+        if k != y.nvec():
+            raise ValueError('Numbers of input and output vectors differ')
+        if not transp:
+            if not isinstance(y, ShardedVectors) or isinstance(x, ShardedVectors):
+                raise ValueError('apply needs replicated input and row-sharded output vectors')
+            if x.dimension() != n or y.dimension() != m:
+                raise ValueError('Matrix and vectors dimensions incompatible')
+            self._loc.apply(x, _LocalView(y), False)
+            return
+        if not isinstance(x, ShardedVectors) or isinstance(y, ShardedVectors):
+            raise ValueError('apply(transp=True) needs row-sharded input and replicated output vectors')
+        if x.dimension() != m or y.dimension() != n:
+            raise ValueError('Matrix and vectors dimensions incompatible')
+        c, L = self._comm, _lib.lib()
+        es = y._es
+        buf = c.reduction_buffer(n * k * es)
+        _lib.check(L.rlh_dense_apply(y._code, self._loc.shape()[0], n, self._loc.data_ptr(), self._loc.lda(), 0, 1, k,
+                                     x.data_ptr(), x.ld(), buf.data_ptr(), n))
+        real = np.dtype(_REAL[np.dtype(self._dtype).type])
+        tdt = c.torch.float32 if real == np.float32 else c.torch.float64
+        nreal = n * k * (2 if np.dtype(self._dtype).kind == 'c' else 1)
+        c.dist.all_reduce(buf[:nreal * real.itemsize].view(tdt), group=c.group)
+        _lib.check(L.rlh_copy(y._code, n, k, buf.data_ptr(), n, y.data_ptr(), y.ld()))
+
+
+class _LocalView:
+    """Presents the local shard of a ShardedVectors to a local operator (dimension = local rows)."""
+
+    def __init__(self, v):
+        self._v = v
+
+    def __getattr__(self, name):
+        return getattr(self._v, name)
+
+    def dimension(self):
+        return self._v.local_dimension()
+
+
+class ShardedAMatrix:
+    """Counterpart of AMatrix (raleigh/algebra/dense_matrix.py) for a row-sharded data matrix."""
+
+    def __init__(self, local_rows, comm, offsets=None):
+        self.__op = ShardedDenseMatrix(local_rows, comm, offsets)
+        self.__comm = comm
+
+    def as_operator(self):
+        return self.__op
+
+    def arch(self):
+        return 'hip'
+
+    def gpu(self):
+        return None
+
+    def data_type(self):
+        return self.__op.data_type()
+
+    def shape(self):
+        return self.__op.shape()
+
+    def order(self):
+        return self.__op.order()
+
+    def frobenius2(self):
+        return self.__op.frobenius2()

@@ -33,13 +33,15 @@ class _OperatorSVD:
         self.shift = shift
         self.time = 0
         m, n = self.op.shape()
-        self.w = v.new_vectors(0, n if transp else m)
+        # vectors are created by the OPERATOR so that a row-sharded matrix can hand out
+        # sharded vectors for its row dimension and replicated ones for its column dimension
+        self.w = self.op.new_vectors(n if transp else m, 0)
         if shift:
             dt = self.op.data_type()
             ones = numpy.ones((1, m), dtype=dt)
-            self.ones = v.new_vectors(1, m)
+            self.ones = self.op.new_vectors(m, 1)
             self.ones.fill(ones)
-            self.aves = v.new_vectors(1, n)
+            self.aves = self.op.new_vectors(n, 1)
             self.op.apply(self.ones, self.aves, transp=True)
             self.aves.scale(m * ones[0, :1])          # column means a
 
@@ -49,7 +51,7 @@ class _OperatorSVD:
         start = time.time()
         if self.transp:
             if self.w.nvec() < k:
-                self.w = x.new_vectors(k, n)
+                self.w = self.op.new_vectors(n, k)
             z = self.w
             z.select(k)
             self.op.apply(x, z, transp=True)
@@ -60,7 +62,7 @@ class _OperatorSVD:
                 y.add(self.ones, -1, z.dot(self.aves))
         else:
             if self.w.nvec() < k:
-                self.w = x.new_vectors(k, m)
+                self.w = self.op.new_vectors(m, k)
             z = self.w
             z.select(k)
             self.op.apply(x, z)
@@ -141,7 +143,7 @@ class PartialSVD:
         self.iterations = solver.iteration
         nv = v.nvec()
         M, N = op.shape()
-        u = v.new_vectors(nv, N if transp else M)
+        u = op.new_vectors(N if transp else M, nv)
         if nv < 1:
             self.sigma = numpy.zeros((0,), dtype=v.data_type())
             self.u, self.v = u, v
@@ -181,13 +183,16 @@ def pca(A, npc=-1, tol=0, verb=0, arch='hip', norm='f', mpc=-1, svtol=1e-3, opt=
     tol : with npc < 0, stop when ||A_s - L R||_F <= tol ||A_s||_F (tol > 0) or <= -tol;
     mpc : cap on the number of components when tol is used;
     svtol : singular value tolerance relative to the largest one.'''
-    if not isinstance(A, numpy.ndarray) or not A.flags['C_CONTIGUOUS']:
-        raise ValueError('matrix must be C_CONTIGUOUS')
     if norm != 'f':
         raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
     if opt is None:
         opt = Options()
-    matrix = AMatrix(A, arch=arch)
+    if hasattr(A, 'as_operator'):       # an AMatrix-like wrap, e.g. dist.ShardedAMatrix (rows sharded)
+        matrix = A
+    else:
+        if not isinstance(A, numpy.ndarray) or not A.flags['C_CONTIGUOUS']:
+            raise ValueError('matrix must be C_CONTIGUOUS')
+        matrix = AMatrix(A, arch=arch)
     m, n = matrix.shape()
     psvd = PartialSVD(matrix, shift=True)
     user_bs, user_cc, user_sc = opt.block_size, opt.convergence_criteria, opt.stopping_criteria
@@ -200,7 +205,7 @@ def pca(A, npc=-1, tol=0, verb=0, arch='hip', norm='f', mpc=-1, svtol=1e-3, opt=
             raise ValueError('either npc or tol must be given (interactive stopping is not available)')
         opSVD = psvd.op_svd()
         # ||A_s||_F^2 = sum_i ||a_i||^2 - m ||mean||^2
-        frob2 = float(numpy.sum(numpy.abs(matrix.dots()))) - m * float(numpy.abs(opSVD.aves.dots(opSVD.aves))[0])
+        frob2 = matrix.frobenius2() - m * float(numpy.abs(opSVD.aves.dots(opSVD.aves))[0])
         opt.stopping_criteria = _FrobeniusStopping(frob2, tol, mpc)
     try:
         psvd.compute(opt, npc)

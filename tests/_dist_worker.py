@@ -94,6 +94,41 @@ def main():
     assert x.shape == (n, 4)
     r = A @ x - x * lmd
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
+    # row-sharded dense operator and PCA (BASELINE config 4 layout): same answer as one rank
+    from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix
+    from raleigh_amd.algebra.hip import Vectors
+    from raleigh_amd.interfaces import pca, pca_error
+    from oracle.pca_data import generate
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((203, 57)).astype(np.float32)
+    Ad = ShardedDenseMatrix.from_global(a, comm)
+    x = rng.standard_normal((4, 57)).astype(np.float32)
+    X = Vectors(x)
+    Yv = Ad.new_vectors(203, 4)
+    Ad.apply(X, Yv)
+    ref = ops.dense_apply(a, x)
+    assert np.linalg.norm(Yv.data() - ref) < 1e-5 * np.linalg.norm(ref)
+    W = Ad.new_vectors(57, 4)
+    Ad.apply(Yv, W, transp=True)
+    ref2 = ops.dense_apply(a, ref, True)
+    assert np.linalg.norm(W.data() - ref2) < 1e-4 * np.linalg.norm(ref2)
+    assert abs(Ad.frobenius2() - float(np.sum(a.astype(np.float64) ** 2))) < 1e-3 * np.sum(a ** 2)
+    np.random.seed(1)
+    A, sigma, u, v = generate(400, 150, 60, pca=True)
+    off = partition(400, size)
+    mat = ShardedAMatrix(A[off[rank]:off[rank + 1], :], comm)
+    np.random.seed(1)
+    mean, trans, comps = pca(mat, npc=12)
+    assert trans.shape == (400, 12) and comps.shape == (12, 150)
+    As = A - A.mean(axis=0, keepdims=True)
+    exact = np.linalg.svd(As.astype(np.float64), compute_uv=False)[:12]
+    sv = np.linalg.norm(trans, axis=0)
+    assert np.max(np.abs(sv - exact) / exact[0]) < 2e-3
+    em, ef = pca_error(A, mean, trans, comps)
+    np.random.seed(1)
+    mean1, trans1, comps1 = pca(A, npc=12)           # the unsharded path on the same data
+    em1, ef1 = pca_error(A, mean1, trans1, comps1)
+    assert abs(ef - ef1) < 0.02 * ef1
     dist.barrier()
     if rank == 0:
         print('DIST_OK world=%d' % size)
