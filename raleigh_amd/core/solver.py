@@ -230,7 +230,9 @@ class Solver:
 
         if m < n // 2:
             try:
-                status = self._iterate(eigenvectors, options, which, extra, init)
+                # the m x m LAPACK/BLAS work is latency-bound: one thread beats the pool by 10-40x
+                with _single_threaded_blas():
+                    status = self._iterate(eigenvectors, options, which, extra, init)
             except _Error as err:
                 if verb > -1:
                     print('%s' % err.value)
@@ -917,6 +919,15 @@ class Solver:
                      abs(self.err_X[0, i]), abs(self.err_X[1, i]), hist.acf[0, i], self.cnv[i]))
 
 
+def _single_threaded_blas():
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=1)
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
 class _Error(Exception):
     def __init__(self, value):
         self.value = value
@@ -982,23 +993,17 @@ def _pivoted_cholesky(G, k, eps):
         S = G
     r = n - k
     kept = 0
-    for i in range(r):
-        d = np.real(np.diag(S)[i:])
-        j = i + int(np.argmax(d))
-        if j != i:
-            S[[i, j], :] = S[[j, i], :]
-            S[:, [i, j]] = S[:, [j, i]]
-            U[:k, [k + i, k + j]] = U[:k, [k + j, k + i]]
-            U[k:k + i, [k + i, k + j]] = U[k:k + i, [k + j, k + i]]
-            ind[k + i], ind[k + j] = ind[k + j], ind[k + i]
-        piv = S[i, i].real
-        if piv <= eps:
-            break
-        row = S[i, i:] / math.sqrt(piv)
-        U[k + i, k + i:] = row
-        if i + 1 < r:
-            S[i + 1:, i + 1:] -= np.outer(row[1:].conj(), row[1:])
-        kept += 1
+    if r > 0:
+        # LAPACK ?pstrf: diagonal-pivoted Cholesky S[P, P] = Us^H Us that stops at the first
+        # pivot <= eps and reports the numerical rank
+        pstrf = sla.get_lapack_funcs('pstrf', (S,))
+        c, piv, kept, info = pstrf(np.ascontiguousarray(S), lower=0, tol=eps)
+        P = piv.astype(np.int64) - 1
+        Us = np.triu(c)
+        Us[kept:, :] = 0
+        U[:k, k:] = U[:k, k:][:, P]
+        U[k:, k:] = Us
+        ind[k:] = [ind[k + int(q)] for q in P]
     # condition control: the reciprocal condition number of the kept Gram block must exceed eps
     while kept > 0:
         sv = np.linalg.svd(U[:k + kept, :k + kept], compute_uv=False)

@@ -27,7 +27,7 @@ if a.profile:
     pr = cProfile.Profile(); pr.enable()
 lmd, x, status = partial_hevp(A, T=True, which=a.k, tol=a.tol, verb=a.verb, opt=opt)
 if a.profile:
-    pr.disable(); pstats.Stats(pr).sort_stats('cumulative').print_stats(25)
+    pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(35)
 el = time.time() - t0
 ana = lap3d_eigenvalues(N, N, N, 1.0, 1.01, 1.02, a.k)
 print('status %d, %d eigenvalues, iterations %d, total %.2fs (solve %.2fs)' % (status, len(lmd), partial_hevp.last['iterations'], el, partial_hevp.last['solve_time']))
