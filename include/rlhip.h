@@ -98,6 +98,21 @@ int rlh_block_update(int dtype, int64_t n, int64_t k, const void *X, int64_t ldx
                      int64_t m, void *Out, int64_t ldo, const void *q,
                      int64_t q_rs, int64_t q_cs, const double *alpha, int beta);
 
+/* ---- fused forms used by this repository's driver; the reference issues the
+ *      same arithmetic as multiply + add (solver.py:1609-1656) and copy + add (solver.py:942-952).
+ * rlh_block_update2: Out[:,j] = beta*Out[:,j] + alpha*(sum_i q1[i,j] X1[:,i] + sum_i q2[i,j] X2[:,i])
+ * in one pass over X1 and X2.
+ * rlh_lincomb_cols: Out[:,i] = a[i]*A[:,i] + b[i]*B[:,i]; a, b HOST arrays of the vectors' dtype;
+ * Out may alias A or B. */
+int rlh_block_update2(int dtype, int64_t n, int64_t k1, const void *X1, int64_t ldx1,
+                      const void *q1, int64_t q1_rs, int64_t q1_cs, int64_t k2,
+                      const void *X2, int64_t ldx2, const void *q2, int64_t q2_rs,
+                      int64_t q2_cs, int64_t m, void *Out, int64_t ldo,
+                      const double *alpha, int beta);
+int rlh_lincomb_cols(int dtype, int64_t n, int64_t m, const void *a, const void *A,
+                     int64_t lda, const void *b, const void *B, int64_t ldb, void *Out,
+                     int64_t ldo);
+
 /* ---- K5: Y += alpha * X on an n x m window (dense_cublas.py:311-316) ---- */
 int rlh_axpy(int dtype, int64_t n, int64_t m, const double *alpha,
              const void *X, int64_t ldx, void *Y, int64_t ldy);

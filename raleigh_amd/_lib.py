@@ -44,6 +44,9 @@ SIGNATURES = {
     'rlh_dots': [_int, _i64, _i64, _p, _i64, _p, _i64, _p, _p],
     'rlh_dots_transp': [_int, _i64, _i64, _p, _i64, _p, _i64, _p],
     'rlh_block_update': [_int, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _int],
+    'rlh_block_update2': [_int, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64,
+                          _p, _int],
+    'rlh_lincomb_cols': [_int, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64],
     'rlh_axpy': [_int, _i64, _i64, _p, _p, _i64, _p, _i64],
     'rlh_axpy_cols': [_int, _i64, _i64, _p, _p, _i64, _p, _i64],
     'rlh_copy': [_int, _i64, _i64, _p, _i64, _p, _i64],

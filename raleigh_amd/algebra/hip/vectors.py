@@ -273,6 +273,38 @@ class Vectors:
             _lib.check(L.rlh_axpy_cols(self._code, self._vdim, m, _lib.host_ptr(sv),
                                        other._ptr(), other._ld, self._ptr(), self._ld))
 
+    # ------------------------------------------------------------ fused forms (not in the reference API)
+    def combine(self, q, other, q_other, output):
+        """output = self * q + other * q_other in one pass over both sources (the reference
+        issues multiply + add, solver.py:1609-1656)."""
+        def prep(a):
+            a = np.asarray(a)
+            if a.dtype.type != self._dtype:
+                a = a.astype(self._dtype)
+            if a.ndim != 2 or any(st < 0 for st in a.strides) or any(st % a.itemsize for st in a.strides):
+                a = np.ascontiguousarray(a)
+            return a
+        q, q2 = prep(q), prep(q_other)
+        m = output.nvec()
+        if q.shape != (self.nvec(), m) or q2.shape != (other.nvec(), m):
+            raise ValueError('coefficient matrices do not match the numbers of vectors')
+        a = np.array([1.0, 0.0], dtype=np.float64)
+        _lib.check(_lib.lib().rlh_block_update2(
+            self._code, self._vdim, q.shape[0], self._ptr(), self._ld, _lib.host_ptr(q),
+            q.strides[0] // q.itemsize, q.strides[1] // q.itemsize,
+            q2.shape[0], other._ptr(), other._ld, _lib.host_ptr(q2),
+            q2.strides[0] // q2.itemsize, q2.strides[1] // q2.itemsize,
+            m, output._ptr(), output._ld, _lib.host_ptr(a), 0))
+
+    def lincomb(self, a, x, b, y):
+        """self[i] = a[i] * x[i] + b[i] * y[i] (a, b scalars or per-vector arrays); self may be x or y.
+        One pass instead of copy + add (solver.py:942-952)."""
+        m = self.nvec()
+        av = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=self._dtype), (m,)))
+        bv = np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=self._dtype), (m,)))
+        _lib.check(_lib.lib().rlh_lincomb_cols(self._code, self._vdim, m, _lib.host_ptr(av), x._ptr(), x._ld,
+                                               _lib.host_ptr(bv), y._ptr(), y._ld, self._ptr(), self._ld))
+
     # ------------------------------------------------------------ other methods of the reference backends
     def shape(self):
         return (self._nvec, self._vdim)

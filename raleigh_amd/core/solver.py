@@ -350,6 +350,8 @@ class Solver:
         hist = _History(m)
 
         opA, opB, opP = problem.A(), problem.B(), self.__P
+        # one-pass forms of multiply+add / copy+add when the Vectors type offers them
+        fused = hasattr(vector, 'combine') and hasattr(vector, 'lincomb')
 
         # ---- work blocks: the active vectors always occupy the first nx slots
         X = vector.new_vectors(m)
@@ -507,8 +509,11 @@ class Solver:
             # ---- residuals W = A X - (B) X lmd, orthogonalised against the locked vectors
             W.select(nx)
             Y.select(nx)
-            AX.copy(W)
-            W.add(BX if gen else X, -lmd[:nx])
+            if fused:           # one pass: W = AX - (B)X diag(lmd)
+                W.lincomb(1.0, AX, -lmd[:nx], BX if gen else X)
+            else:
+                AX.copy(W)
+                W.add(BX if gen else X, -lmd[:nx])
             if Xc.nvec() > 0:
                 project_out_locked(W, BXc if pro else Xc, BXc if gen else Xc)
             if pro:
@@ -647,7 +652,9 @@ class Solver:
             select_all(ny, W, Y)
             if not pro:
                 if opP is None:
-                    W.copy(Y)
+                    Y, W = W, Y         # the residuals ARE the search directions: swap, no copy
+                    if std:
+                        BY = Y
                 else:
                     opP.apply(W, Y)
             # the active block shrinks by the locked pairs
@@ -831,21 +838,30 @@ class Solver:
             def combine(SX, SY, out, coef):
                 """out = SX * coef[:nx_act] + SY * coef[nx_act:]."""
                 out.select(coef.shape[1])
-                if nx_act > 0:
+                if nx_act > 0 and fused:
+                    SX.combine(coef[:nx_act], SY, coef[nx_act:], out)
+                elif nx_act > 0:
                     SX.multiply(np.ascontiguousarray(coef[:nx_act]), out)
                     out.add(SY, 1.0, np.ascontiguousarray(coef[nx_act:]))
                 else:
                     SY.multiply(np.ascontiguousarray(coef[nx_act:]), out)
 
-            triples = [(AX, AY, AZ), (X, Y, Z)] if std else [(AX, AY, AZ), (BX, BY, BZ), (X, Y, Z)]
-            for SX, SY, SZ in triples:
+            # the new block is written into the scratch block W, which then changes places with
+            # the old one (no copy back); the old storage is the scratch of the next triple
+            results = {}
+            names = ['AX', 'X'] if std else ['AX', 'BX', 'X']
+            olds = {'AX': (AX, AY, AZ), 'BX': (BX, BY, BZ), 'X': (X, Y, Z)}
+            for name in names:
+                SX, SY, SZ = olds[name]
                 if nz > 0:
                     SZ.select(m)
                     combine(SX, SY, SZ, QZ)
                 W.select(m)
                 combine(SX, SY, W, QX)
-                SX.select(nx_new, 0)
-                W.copy(SX)
+                results[name] = W
+                W = SX
+            AX, X = results['AX'], results['X']
+            BX = X if std else results['BX']
             select_all(m, Y, AY, BY, W)
 
             nx, leftX, rightX = nx_new, leftX_new, rightX_new

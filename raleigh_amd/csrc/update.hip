@@ -18,8 +18,10 @@ namespace rlh {
 
 constexpr int kUnrollK = 4;
 
+// Two sources: Out = beta*Out + X*Q[0:kpad] + X2*Q[kpad:kpad+k2] in ONE pass (k2 = 0: one source).
 template <typename T, int JT, bool BETA>
 __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__ X, int64_t ldx,
+                                                           const T *__restrict__ X2, int64_t ldx2, int k2, int kpad,
                                                            T *__restrict__ Out, int64_t ldo,
                                                            const T *__restrict__ Q, int ldq, int64_t n, int k,
                                                            int m) {
@@ -47,6 +49,18 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
 #pragma unroll
         for (int j = 0; j < JT; ++j) fma_acc(acc[j], x[u], Qp[(i + u) * ldq + j]);
     }
+    for (int i = 0; i < k2; i += kUnrollK) {
+      T x[kUnrollK];
+#pragma unroll
+      for (int u = 0; u < kUnrollK; ++u) {
+        const int col = (i + u) < k2 ? (i + u) : (k2 - 1);
+        x[u] = X2[row + (int64_t)col * ldx2];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnrollK; ++u)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) fma_acc(acc[j], x[u], Qp[(kpad + i + u) * ldq + j]);
+    }
 #pragma unroll
     for (int j = 0; j < JT; ++j)
       if (j < jv) Op[row + (int64_t)j * ldo] = acc[j];
@@ -67,18 +81,18 @@ template <> struct HostScalar<c64> {
 
 template <typename T, int JT>
 static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
-                         int beta) {
+                         int beta, const T *X2 = nullptr, int64_t ldx2 = 0, int k2 = 0, int kpad = 0) {
   Context &c = ctx();
   int64_t nbx = (n + 255) / 256;
   const int64_t cap = (int64_t)c.num_cu * 8;
   if (nbx > cap) nbx = cap;
   dim3 grid((unsigned)nbx, (unsigned)((m + JT - 1) / JT));
   if (beta)
-    hipLaunchKernelGGL((block_update_kernel<T, JT, true>), grid, dim3(256), 0, c.stream, X, ldx, Out, ldo, Qd, ldq, n,
-                       k, m);
+    hipLaunchKernelGGL((block_update_kernel<T, JT, true>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
+                       Out, ldo, Qd, ldq, n, k, m);
   else
-    hipLaunchKernelGGL((block_update_kernel<T, JT, false>), grid, dim3(256), 0, c.stream, X, ldx, Out, ldo, Qd, ldq,
-                       n, k, m);
+    hipLaunchKernelGGL((block_update_kernel<T, JT, false>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
+                       Out, ldo, Qd, ldq, n, k, m);
   RLH_HIP(hipGetLastError());
   return 0;
 }
@@ -128,6 +142,80 @@ static int block_update_impl(int64_t n, int64_t k, const void *X_, int64_t ldx, 
     if (k == 0) break;
   }
   return 0;
+}
+
+template <int DT>
+static int block_update2_impl(int64_t n, int64_t k1, const void *X1_, int64_t ldx1, const void *q1_, int64_t q1_rs,
+                              int64_t q1_cs, int64_t k2, const void *X2_, int64_t ldx2, const void *q2_,
+                              int64_t q2_rs, int64_t q2_cs, int64_t m, void *Out_, int64_t ldo, const double *alpha,
+                              int beta) {
+  using T = typename DType<DT>::T;
+  constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
+  const T *q1 = (const T *)q1_, *q2 = (const T *)q2_;
+  const int JT = (m <= 8) ? 8 : ((m <= 16 || JTMAX == 16) ? 16 : 32);
+  const int64_t mpad = (m + JT - 1) / JT * JT;
+  const int64_t kp1 = (k1 + kUnrollK - 1) / kUnrollK * kUnrollK, kp2 = (k2 + kUnrollK - 1) / kUnrollK * kUnrollK;
+  const size_t bytes = (size_t)((kp1 + kp2) * mpad) * sizeof(T);
+  RLH_REQUIRE(bytes <= kRingSlotBytes, "rlh_block_update2: coefficient blocks of %zu bytes exceed the staging slot",
+              bytes);
+  int slot; void *h, *d;
+  if (int rc = ring_acquire(bytes, &slot, &h, &d)) return rc;
+  T *qh = (T *)h;
+  memset(qh, 0, bytes);
+  for (int64_t i = 0; i < k1; ++i)
+    for (int64_t j = 0; j < m; ++j) qh[i * mpad + j] = HostScalar<T>::mul(alpha, q1[i * q1_rs + j * q1_cs]);
+  for (int64_t i = 0; i < k2; ++i)
+    for (int64_t j = 0; j < m; ++j) qh[(kp1 + i) * mpad + j] = HostScalar<T>::mul(alpha, q2[i * q2_rs + j * q2_cs]);
+  if (int rc = ring_commit(slot, bytes)) return rc;
+  const T *X1 = (const T *)X1_, *X2 = (const T *)X2_;
+  T *Out = (T *)Out_;
+  int rc;
+  if (JT == 8)
+    rc = launch_update<T, 8>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m, beta, X2, ldx2, (int)k2,
+                             (int)kp1);
+  else if (JT == 16)
+    rc = launch_update<T, 16>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m, beta, X2, ldx2,
+                              (int)k2, (int)kp1);
+  else
+    rc = launch_update<T, (JTMAX == 32 ? 32 : 16)>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m,
+                                                   beta, X2, ldx2, (int)k2, (int)kp1);
+  if (rc) return rc;
+  return ring_release(slot);
+}
+
+// Out[:, i] = a[i] * A[:, i] + b[i] * B[:, i]   (residual W = AX - X diag(lmd) in one pass)
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void lincomb_cols_kernel(const T *A, int64_t lda,
+                                                           const T *B, int64_t ldb, T *Out,
+                                                           int64_t ldo, const T *__restrict__ coef, int m, int64_t n) {
+  constexpr int VEC = ALIGNED ? 16 / (int)sizeof(T) : 1;
+  struct alignas(ALIGNED ? 16 : alignof(T)) V { T v[VEC]; };
+  const int col = blockIdx.y;
+  const T ca = coef[col], cb = coef[m + col];
+  const T *a = A + (int64_t)col * lda;
+  const T *b = B + (int64_t)col * ldb;
+  T *o = Out + (int64_t)col * ldo;
+  const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
+  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
+    if (r + VEC <= n) {
+      const V av = *reinterpret_cast<const V *>(a + r);
+      const V bv = *reinterpret_cast<const V *>(b + r);
+      V ov;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T t = mul_of(ca, av.v[e]);
+        fma_acc(t, cb, bv.v[e]);
+        ov.v[e] = t;
+      }
+      *reinterpret_cast<V *>(o + r) = ov;
+    } else {
+      for (int e = 0; e < VEC && r + e < n; ++e) {
+        T t = mul_of(ca, a[r + e]);
+        fma_acc(t, cb, b[r + e]);
+        o[r + e] = t;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- column-wise elementwise kernels
@@ -244,6 +332,26 @@ static int axpy_cols_impl(int64_t n, int64_t m, const void *s_, bool broadcast, 
 }
 
 template <int DT>
+static int lincomb_cols_impl(int64_t n, int64_t m, const void *a_, const void *A, int64_t lda, const void *b_,
+                             const void *B, int64_t ldb, void *Out, int64_t ldo) {
+  using T = typename DType<DT>::T;
+  const T *a = (const T *)a_, *b = (const T *)b_;
+  int slot; const T *cd;
+  if (int rc = stage_coeffs<T>(2 * m, [&](int64_t i) { return i < m ? a[i] : b[i - m]; }, &slot, &cd)) return rc;
+  const bool al = aligned16(A, lda, sizeof(T)) && aligned16(B, ldb, sizeof(T)) && aligned16(Out, ldo, sizeof(T));
+  const int vec = al ? 16 / (int)sizeof(T) : 1;
+  dim3 grid(row_blocks((n + vec - 1) / vec, m), (unsigned)m);
+  if (al)
+    hipLaunchKernelGGL((lincomb_cols_kernel<T, true>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
+                       (const T *)B, ldb, (T *)Out, ldo, cd, (int)m, n);
+  else
+    hipLaunchKernelGGL((lincomb_cols_kernel<T, false>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
+                       (const T *)B, ldb, (T *)Out, ldo, cd, (int)m, n);
+  RLH_HIP(hipGetLastError());
+  return ring_release(slot);
+}
+
+template <int DT>
 static int scale_cols_impl(int64_t n, int64_t m, const double *s, int mode, void *X, int64_t ldx) {
   using T = typename DType<DT>::T;
   using R = typename DType<DT>::R;
@@ -337,6 +445,39 @@ int rlh_block_update(int dtype, int64_t n, int64_t k, const void *X, int64_t ldx
               "rlh_block_update: output window overlaps the input window");
   int rc = 0;
   RLH_DISPATCH(dtype, block_update_impl, n, k, X, ldx, m, Out, ldo, q, q_rs, q_cs, alpha, beta)
+  return rc;
+}
+
+int rlh_block_update2(int dtype, int64_t n, int64_t k1, const void *X1, int64_t ldx1, const void *q1, int64_t q1_rs,
+                      int64_t q1_cs, int64_t k2, const void *X2, int64_t ldx2, const void *q2, int64_t q2_rs,
+                      int64_t q2_cs, int64_t m, void *Out, int64_t ldo, const double *alpha, int beta) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_block_update2: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && k1 >= 1 && k2 >= 1 && m >= 0, "rlh_block_update2: bad size");
+  RLH_REQUIRE(beta == 0 || beta == 1, "rlh_block_update2: beta must be 0 or 1");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(Out && alpha && X1 && X2 && q1 && q2, "rlh_block_update2: null pointer");
+  RLH_REQUIRE(ldo >= n && ldx1 >= n && ldx2 >= n, "rlh_block_update2: leading dimension smaller than n");
+  const int64_t es = dtype_size(dtype);
+  RLH_REQUIRE(!overlaps(X1, ((k1 - 1) * ldx1 + n) * es, Out, ((m - 1) * ldo + n) * es) &&
+                  !overlaps(X2, ((k2 - 1) * ldx2 + n) * es, Out, ((m - 1) * ldo + n) * es),
+              "rlh_block_update2: output window overlaps an input window");
+  int rc = 0;
+  RLH_DISPATCH(dtype, block_update2_impl, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, m, Out,
+               ldo, alpha, beta)
+  return rc;
+}
+
+int rlh_lincomb_cols(int dtype, int64_t n, int64_t m, const void *a, const void *A, int64_t lda, const void *b,
+                     const void *B, int64_t ldb, void *Out, int64_t ldo) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_lincomb_cols: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_lincomb_cols: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(a && b && A && B && Out, "rlh_lincomb_cols: null pointer");
+  RLH_REQUIRE(lda >= n && ldb >= n && ldo >= n, "rlh_lincomb_cols: leading dimension smaller than n");
+  int rc = 0;
+  RLH_DISPATCH(dtype, lincomb_cols_impl, n, m, a, A, lda, b, B, ldb, Out, ldo)
   return rc;
 }
 

@@ -77,6 +77,19 @@ def ops_case(golden_dir, key, shape):
     u.multiply(p, w)
     w.add(u, -1.0, p)
     assert np.linalg.norm(w.data()) < 10 * tol * np.linalg.norm(g['multiply'])
+    # fused forms: combine == multiply + add, lincomb == copy + add (checked against the golden add results)
+    w = Vectors(g['v'].copy())
+    w2 = Vectors(g['v'].copy())
+    u.multiply(q, w2)
+    w2.add(v, 1.0, np.asfortranarray(q))
+    u.combine(q, v, np.asfortranarray(q), w)
+    assert rel(w.data(), w2.data()) < tol
+    w = Vectors(g['v'].copy())
+    w.lincomb(1.0, v, g['s_vec'], u)
+    assert rel(w.data(), g['add_vector']) < tol
+    w = Vectors(g['v'].copy())
+    w.lincomb(1.0, w, -0.75, u)            # aliasing the output with an input
+    assert rel(w.data(), g['add_scalar']) < tol
     # scale
     w = Vectors(g['u'].copy())
     w.scale(g['scale_s'], multiply=True)

@@ -175,6 +175,33 @@ class FakeLib:
         out[:, :] = (out + upd if beta else upd).astype(dt)
         return 0
 
+    def rlh_block_update2(self, code, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, m, Out, ldo,
+                          alpha, beta):
+        self._count('block_update2')
+        if n == 0 or m == 0:
+            return 0
+        dt = np.dtype(_DT[code])
+        a = _flat(alpha, np.float64, 2)
+        al = complex(a[0], a[1]) if dt.kind == 'c' else a[0]
+
+        def qmat(q, k, rs, cs):
+            qf = _flat(q, dt, (k - 1) * rs + (m - 1) * cs + 1)
+            return np.lib.stride_tricks.as_strided(qf, shape=(k, m), strides=(rs * dt.itemsize, cs * dt.itemsize))
+        upd = (al * qmat(q1, k1, q1_rs, q1_cs)).T @ _block(X1, code, n, k1, ldx1) \
+            + (al * qmat(q2, k2, q2_rs, q2_cs)).T @ _block(X2, code, n, k2, ldx2)
+        out = _block(Out, code, n, m, ldo)
+        out[:, :] = (out + upd if beta else upd).astype(dt)
+        return 0
+
+    def rlh_lincomb_cols(self, code, n, m, a, A, lda, b, B, ldb, Out, ldo):
+        self._count('lincomb_cols')
+        if n == 0 or m == 0:
+            return 0
+        av, bv = _flat(a, _DT[code], m), _flat(b, _DT[code], m)
+        res = av[:, None] * _block(A, code, n, m, lda) + bv[:, None] * _block(B, code, n, m, ldb)
+        _block(Out, code, n, m, ldo)[:, :] = res.astype(_DT[code])
+        return 0
+
     def rlh_axpy(self, code, n, m, alpha, X, ldx, Y, ldy):
         self._count('axpy')
         dt = np.dtype(_DT[code])
