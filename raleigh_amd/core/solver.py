@@ -725,14 +725,23 @@ class Solver:
                 return 3
             nxy = nx_act + ny
             U = U[:nxy, :nxy]
-            order = np.asarray(ind[nx_act:nxy]) - nx_act
-            if dropped > 0 or np.any(order != np.arange(ny)):
+            # Pivoting permutes the search directions.  Only when some are DROPPED are the kept ones
+            # gathered (into the scratch block, which then changes places with Y); otherwise Y stays
+            # where it is and the permutation is applied to the small host matrices instead.
+            perm = np.asarray(ind[nx_act:nxy], dtype=np.int64) - nx_act
+            if dropped > 0:
                 W.select(ny)
-                for V in ((Y,) if std else (Y, BY)):
-                    V.select(ny_old)
-                    V.copy(W, order)
-                    V.select(ny)
-                    W.copy(V)
+                Y.select(ny_old)
+                Y.copy(W, perm)
+                Y, W = W, Y
+                if std:
+                    BY = Y
+                else:
+                    W.select(ny)
+                    BY.select(ny_old)
+                    BY.copy(W, perm)
+                    BY, W = W, BY
+                perm = np.arange(ny, dtype=np.int64)
             select_all(ny, Y, AY, BY)
 
             # ---- A-Gram matrix of (X, Y) and the Rayleigh-Ritz problem in the Cholesky basis
@@ -744,6 +753,9 @@ class Solver:
                 opA.apply(Y, AY)
                 YAY = AY.dot(Y)
                 XAY = AY.dot(X) if nx_act > 0 else None
+            YAY = YAY[np.ix_(perm, perm)]                     # to the pivoted order of U
+            if nx_act > 0:
+                XAY = XAY[:, perm]
             GA = np.block([[XAX, XAY], [XAY.conj().T, YAY]]) if nx_act > 0 else YAY
             Uh = U.conj().T
             G = sla.solve_triangular(Uh, sla.solve_triangular(Uh, GA, lower=True).conj().T, lower=True)
@@ -828,6 +840,9 @@ class Solver:
 
             # ---- new X and the next "previous directions" Z from the Ritz vectors
             Q = sla.solve_triangular(U, Q)
+            Qphys = Q.copy()                                  # rows back to the physical order of Y
+            Qphys[nx_act + perm] = Q[nx_act:]
+            Q = Qphys
             take = np.concatenate((np.arange(leftX_new), np.arange(nxy - rightX_new, nxy))).astype(np.int64)
             rest = np.arange(leftX_new, nxy - rightX_new)
             lmdx = lmdxy[take]

@@ -208,13 +208,15 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     }
     __syncthreads();
   }
-  R *out = reinterpret_cast<R *>(a.partials) + ((int64_t)panel * gridDim.x + blockIdx.x) * (VY * VX);
-  for (int e = tid; e < VY * VX; e += 256) out[e] = lds[e];
+  // partials are laid out [panel][entry][workgroup] so that the finalize kernel reads the
+  // contributions to one entry as one contiguous run
+  R *out = reinterpret_cast<R *>(a.partials) + (int64_t)panel * (VY * VX) * gridDim.x + blockIdx.x;
+  for (int e = tid; e < VY * VX; e += 256) out[(int64_t)e * gridDim.x] = lds[e];
 }
 
-// Sums the per-workgroup partials in a fixed order (16 strided lanes per output, then a
-// serial 16-term sum) and writes the (my, mx) result; complex outputs recombine the four
-// real Gram entries conj(y)*x = (RR + II) + i (RI - IR).
+// Sums the per-workgroup partials of every Gram entry in a fixed order (one wavefront per
+// entry: 64 strided partial sums, then a fixed xor-shuffle tree) and writes the (my, mx)
+// result; complex outputs recombine conj(y)*x = (RR + II) + i (RI - IR).
 template <int DT>
 __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int nbx, int npj, int VY, int VX, int my,
                                                      int mx, void *out_) {
@@ -222,33 +224,26 @@ __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int 
   using R = typename DType<DT>::R;
   constexpr bool CPLX = DType<DT>::cplx;
   constexpr int NCOMP = CPLX ? 4 : 1;
-  __shared__ double red[NCOMP][16][17];
   const R *partials = reinterpret_cast<const R *>(partials_);
-  const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + o;
-  const bool valid = e < my * mx;
-  const int i = valid ? e / mx : 0, j = valid ? e % mx : 0;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per output entry
+  if (e >= my * mx) return;
+  const int i = e / mx, j = e % mx;
   const int64_t slab = (int64_t)VY * VX;
+  double t[NCOMP];
 #pragma unroll
   for (int comp = 0; comp < NCOMP; ++comp) {
     const int vi = CPLX ? 2 * i + (comp >> 1) : i;     // comp: 0 RR, 1 RI, 2 IR, 3 II
     const int vj = CPLX ? 2 * j + (comp & 1) : j;
     const int panel = (vi / VY) * npj + (vj / VX);
-    const R *p = partials + (int64_t)panel * nbx * slab + (vi % VY) * VX + (vj % VX);
+    const R *p = partials + ((int64_t)panel * slab + (vi % VY) * VX + (vj % VX)) * nbx;
     double s = 0.0;
-    if (valid)
-      for (int b = l; b < nbx; b += 16) s += (double)p[(int64_t)b * slab];
-    red[comp][l][o] = s;
-  }
-  __syncthreads();
-  if (l == 0 && valid) {
-    double t[NCOMP];
+    for (int b = lane; b < nbx; b += 64) s += (double)p[b];
 #pragma unroll
-    for (int comp = 0; comp < NCOMP; ++comp) {
-      double acc = 0.0;
-      for (int ll = 0; ll < 16; ++ll) acc += red[comp][ll][o];
-      t[comp] = acc;
-    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    t[comp] = s;
+  }
+  if (lane == 0) {
     T *out = reinterpret_cast<T *>(out_);
     if constexpr (!CPLX) {
       out[e] = (R)t[0];
@@ -298,7 +293,7 @@ static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, vo
                      c.stream, a);
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
-  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 15) / 16), dim3(256), 0, c.stream, c.work, (int)nbx, npj, VY,
+  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nbx, npj, VY,
                      VX, (int)my, (int)mx, d_out);
   RLH_HIP(hipGetLastError());
   return 0;
@@ -365,12 +360,51 @@ __global__ __launch_bounds__(256) void dots_kernel(const T *X, int64_t ldx, cons
 }
 
 template <typename T>
-__global__ void dots_finalize(const T *partials, int nbx, int m, T *out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void dots_finalize(const T *partials, int nbx, int m, T *out) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per column
   if (col >= m) return;
   T s = zero_of(T{});
-  for (int b = 0; b < nbx; ++b) s = add_of(s, partials[(int64_t)col * nbx + b]);
-  out[col] = s;
+  for (int b = lane; b < nbx; b += 64) s = add_of(s, partials[(int64_t)col * nbx + b]);
+  // fixed xor-shuffle tree over the 64 lanes (deterministic)
+  if constexpr (sizeof(T) == sizeof(float) || sizeof(T) == sizeof(double)) {
+    using R = T;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s = s + (R)__shfl_xor(s, off);
+  }
+  if (lane == 0) out[col] = s;
+}
+
+template <typename R2, typename C>
+__device__ __forceinline__ C shfl_complex(C v, int off) {
+  C r;
+  r.re = __shfl_xor(v.re, off);
+  r.im = __shfl_xor(v.im, off);
+  return r;
+}
+
+template <>
+__global__ __launch_bounds__(256) void dots_finalize<c32>(const c32 *partials, int nbx, int m, c32 *out) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= m) return;
+  c32 s = zero_of(c32{});
+  for (int b = lane; b < nbx; b += 64) s = add_of(s, partials[(int64_t)col * nbx + b]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s = add_of(s, shfl_complex<float>(s, off));
+  if (lane == 0) out[col] = s;
+}
+
+template <>
+__global__ __launch_bounds__(256) void dots_finalize<c64>(const c64 *partials, int nbx, int m, c64 *out) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= m) return;
+  c64 s = zero_of(c64{});
+  for (int b = lane; b < nbx; b += 64) s = add_of(s, partials[(int64_t)col * nbx + b]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s = add_of(s, shfl_complex<double>(s, off));
+  if (lane == 0) out[col] = s;
 }
 
 template <int DT>
@@ -392,7 +426,7 @@ static int dots_impl(int64_t n, int64_t m, const void *X, int64_t ldx, const voi
     hipLaunchKernelGGL((dots_kernel<T, false>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
                        n, (T *)c.work, (int)nbx);
   RLH_HIP(hipGetLastError());
-  hipLaunchKernelGGL((dots_finalize<T>), dim3(((int)m + 63) / 64), dim3(64), 0, c.stream, (const T *)c.work,
+  hipLaunchKernelGGL((dots_finalize<T>), dim3(((int)m + 3) / 4), dim3(256), 0, c.stream, (const T *)c.work,
                      (int)nbx, (int)m, (T *)d_out);
   RLH_HIP(hipGetLastError());
   return 0;

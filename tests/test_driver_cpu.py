@@ -205,4 +205,4 @@ def test_complex_hermitian_shift_invert_config5_shape():
     for e in nearest[:6]:
         assert np.min(np.abs(lmd - e)) < 1e-10 * abs(e)
     r = H @ x - x * lmd
-    assert np.max(np.linalg.norm(r, axis=0)) < 1e-6
+    assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
