@@ -104,7 +104,8 @@ struct Context {
   char *work = nullptr;
   char *result_d = nullptr;
   size_t result_d_bytes = 0;
-  char *result_h = nullptr;      // pinned
+  char *result_h = nullptr;      // pinned, mapped into the device address space
+  char *result_hd = nullptr;     // device-side address of result_h (zero-copy result delivery)
   size_t result_h_bytes = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr;
 };

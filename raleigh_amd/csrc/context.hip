@@ -69,9 +69,10 @@ int ensure_result(size_t bytes) {
     RLH_HIP(hipStreamSynchronize(c.stream));
     if (c.result_d) RLH_HIP(hipFree(c.result_d));
     if (c.result_h) RLH_HIP(hipHostFree(c.result_h));
-    c.result_d = nullptr; c.result_h = nullptr; c.result_d_bytes = c.result_h_bytes = 0;
+    c.result_d = nullptr; c.result_h = nullptr; c.result_hd = nullptr; c.result_d_bytes = c.result_h_bytes = 0;
     RLH_HIP(hipMalloc((void **)&c.result_d, nb));
-    RLH_HIP(hipHostMalloc((void **)&c.result_h, nb, hipHostMallocDefault));
+    RLH_HIP(hipHostMalloc((void **)&c.result_h, nb, hipHostMallocMapped));
+    RLH_HIP(hipHostGetDevicePointer((void **)&c.result_hd, c.result_h, 0));
     c.result_d_bytes = c.result_h_bytes = nb;
   }
   return 0;
@@ -80,7 +81,11 @@ int ensure_result(size_t bytes) {
 int fetch_result(void *h_out, const void *d_src, size_t bytes) {
   Context &c = ctx();
   if (bytes == 0) return 0;
-  if (bytes <= c.result_h_bytes) {
+  if (d_src == c.result_hd && bytes <= c.result_h_bytes) {
+    // the finalize kernel has written straight into the mapped pinned buffer: no copy launch
+    RLH_HIP(hipStreamSynchronize(c.stream));
+    memcpy(h_out, c.result_h, bytes);
+  } else if (bytes <= c.result_h_bytes) {
     RLH_HIP(hipMemcpyAsync(c.result_h, d_src, bytes, hipMemcpyDeviceToHost, c.stream));
     RLH_HIP(hipStreamSynchronize(c.stream));
     memcpy(h_out, c.result_h, bytes);

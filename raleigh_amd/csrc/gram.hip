@@ -485,7 +485,7 @@ int rlh_gram(int dtype, int64_t n, int64_t mx, const void *X, int64_t ldx, int64
   const size_t bytes = (size_t)(mx * my * dtype_size(dtype));
   if (!d_out) {
     if (int rc = ensure_result(bytes)) return rc;
-    d_out = ctx().result_d;
+    d_out = ctx().result_hd;          // small result: written by the finalize kernel into mapped host memory
   }
   int rc = 0;
   if (n == 0) {
@@ -511,7 +511,7 @@ int rlh_dots(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, const 
   const size_t bytes = (size_t)(m * dtype_size(dtype));
   if (!d_out) {
     if (int rc = ensure_result(bytes)) return rc;
-    d_out = ctx().result_d;
+    d_out = ctx().result_hd;          // small result: written by the finalize kernel into mapped host memory
   }
   int rc = 0;
   if (n == 0) {
