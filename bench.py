@@ -7,8 +7,10 @@ BASELINE.json), m = 32, fp64, A = 7-point 3-D Laplacian.
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the rows
-are sharded over the ranks (strong scaling: the global problem is fixed), every
-Gram / dots carries one all-reduce, the SpMM one halo exchange.
+are sharded over the ranks, every Gram / dots carries one all-reduce, the SpMM
+one halo exchange.  Weak scaling: every GPU holds a 215^3-row shard (the grid
+grows along z: 215 x 215 x 215 N), so per-GPU work is fixed and `value` is the
+aggregate over the N GPUs.
 
 Prints ONE JSON line (rank 0).  `value` = algorithmic GB/s of the whole job:
 bytes of SURVEY 8(d) (9 Gram calls = 16 blocks, 4 self-dots = 4 blocks, one
@@ -178,6 +180,12 @@ def main():
                     help='lap3d side of the end-to-end "seconds to 10 eigenpairs" run (0: skip)')
     args = ap.parse_args()
 
+    # Everything any library prints (RCCL prints a version banner on stdout) goes to stderr;
+    # the real stdout carries exactly one JSON line, written at the very end by rank 0.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -200,8 +208,9 @@ def main():
     L = _lib.lib(local_rank)
 
     side, m, es = args.side, args.m, 8
-    n = side ** 3
-    nnz = 7 * n - 2 * (side * side * 3)          # 7-point stencil minus the faces
+    nzg = side * world                           # weak scaling: the grid grows along z with the GPUs
+    n = side * side * nzg
+    nnz = 7 * n - 2 * (side * nzg * 2 + side * side)      # 7-point stencil minus the six faces
     if comm is None:
         r0, r1 = 0, n
     else:
@@ -222,8 +231,8 @@ def main():
     for i, b in enumerate(blocks[1:], 1):         # distinct random-looking blocks from device-side ops
         blocks[0].copy(b, np.roll(np.arange(m), i))
         b.add(blocks[0], 0.37 * i)
-    rows = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, r0, r1)
-    assert comm is not None or rows.nnz == nnz
+    rows = lap3d_rows(side, side, nzg, 1.0, 1.01, 1.02 * world, r0, r1)
+    assert world > 1 or rows.nnz == nnz
     if comm is None:
         csr = CsrOperator(rows)
 
@@ -293,9 +302,10 @@ def main():
     out = {'metric': 'inner-iter GB/s vs HBM roofline (Gram+dots+SpMM of one block-JCG iteration)',
            'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-           'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-           'config': {'workload': 'block-JCG inner iteration: 9 Gram + 4 dots + 1 SpMM, n=%d^3=%d rows, m=%d, '
-                                  '7-pt Laplacian nnz=%d, rows sharded over %d GPU(s)' % (side, n, m, nnz, world),
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': 'block-JCG inner iteration: 9 Gram + 4 dots + 1 SpMM, n=%dx%dx%d=%d rows '
+                                  '(%d^3 per GPU), m=%d, 7-pt Laplacian nnz=%d, rows sharded over %d GPU(s)'
+                                  % (side, side, nzg, n, side, m, nnz, world),
                       'n': n, 'm': m, 'nnz': nnz, 'algorithmic_bytes_per_step': nbytes,
                       'bytes_breakdown': parts},
            'roofline': roofline}
@@ -304,7 +314,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(m)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if comm is not None:
         comm.dist.destroy_process_group()
 

@@ -55,6 +55,7 @@ class Comm:
         else:
             self.device = torch.device('cpu')
         self._red = None
+        self._host = None
 
     def buffer(self, nbytes):
         """A communication buffer (device memory under RCCL, host memory under gloo)."""
@@ -73,8 +74,16 @@ class Comm:
         tdt = self.torch.float32 if real == np.float32 else self.torch.float64
         view = buf[:nreal * real.itemsize].view(tdt)
         self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
-        host = view.cpu().numpy() if self.on_device else view.numpy().copy()
-        return host.view(np_dtype)
+        if not self.on_device:
+            return view.numpy().copy().view(np_dtype)
+        # pinned staging buffer + one stream synchronisation (no pageable-memory bounce)
+        nbytes = nreal * real.itemsize
+        if self._host is None or self._host.numel() < nbytes:
+            self._host = self.torch.empty(max(nbytes, 1 << 16), dtype=self.torch.uint8, pin_memory=True)
+        hview = self._host[:nbytes].view(tdt)
+        hview.copy_(view, non_blocking=True)
+        self.stream.synchronize()
+        return hview.numpy().copy().view(np_dtype)
 
     def barrier(self):
         self.dist.barrier(group=self.group)
