@@ -133,5 +133,8 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
     if eigenvectors.nvec() > 0:
         x = x[:, ind]
     partial_hevp.last = {'iterations': evp_solver.iteration, 'solve_time': solve_time,
-                         'residual_norms': evp_solver.residual_norms[ind] if len(ind) else None}
+                         'residual_norms': evp_solver.residual_norms[ind] if len(ind) else None,
+                         'convergence_status': evp_solver.convergence_status[ind] if len(ind) else None,
+                         'eigenvector_errors': (evp_solver.eigenvector_errors.kinematic[ind],
+                                                evp_solver.eigenvector_errors.residual[ind]) if len(ind) else None}
     return lmd, x, status

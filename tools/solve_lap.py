@@ -32,3 +32,8 @@ el = time.time() - t0
 ana = lap3d_eigenvalues(N, N, N, 1.0, 1.01, 1.02, a.k)
 print('status %d, %d eigenvalues, iterations %d, total %.2fs (solve %.2fs)' % (status, len(lmd), partial_hevp.last['iterations'], el, partial_hevp.last['solve_time']))
 print('max rel eigenvalue error vs analytic: %.2e' % np.max(np.abs(lmd[:a.k] - ana) / ana))
+print('convergence status:', partial_hevp.last['convergence_status'])
+print('residual norms:', np.array2string(np.asarray(partial_hevp.last['residual_norms']), precision=2))
+print('eigvec err (kinematic):', np.array2string(partial_hevp.last['eigenvector_errors'][0], precision=2))
+print('eigvec err (residual):', np.array2string(partial_hevp.last['eigenvector_errors'][1], precision=2))
+print('rel eigenvalue errors:', np.array2string(np.abs(lmd[:a.k] - ana) / ana, precision=2))
