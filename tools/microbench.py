@@ -19,6 +19,8 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--lap', type=int, default=0, help='lap3d side N (n = N^3) for the SpMM line')
     ap.add_argument('--only', default='')
+    ap.add_argument('--lap2d', type=int, default=0, help='2-D Laplacian side (n = N^2), SpMM line only')
+    ap.add_argument('--band', type=int, default=-1, help='banded test matrix with diagonals -band..band (needs --n)')
     args = ap.parse_args()
     from raleigh_amd import _lib
     from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
@@ -28,6 +30,8 @@ def main():
     n, m = args.n, args.m
     if args.lap:
         n = args.lap ** 3
+    if args.lap2d:
+        n = args.lap2d ** 2
     code = _lib.dtype_code(dt)
     X, Y, W = Vectors(n, m, data_type=dt), Vectors(n, m, data_type=dt), Vectors(n, m, data_type=dt)
     # device-side fill: upload one random column block and replicate (host RNG for 10^7 x 32 is slow)
@@ -76,10 +80,18 @@ def main():
             continue
         med, mn = timed(fn)
         print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % (name, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
-    if args.lap and args.dtype in 'd':
+    if args.band >= 0 and args.dtype in 'd':
+        import scipy.sparse as sp
+        offs = list(range(-args.band, args.band + 1))
+        A = sp.diags([np.full(n - abs(o), 1.0 + 0.1 * o) for o in offs], offs, shape=(n, n), format='csr')
+        op = SparseSymmetricMatrix(A)
+        nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
+        med, mn = timed(lambda: op.apply(X, W))
+        print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % ('spmm band %d' % args.band, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
+    if (args.lap or args.lap2d) and args.dtype in 'd':
         from oracle.sparse import lap3d
         t0 = time.time()
-        A = lap3d(args.lap, args.lap, args.lap, 1.0, 1.01, 1.02)
+        A = lap3d(args.lap, args.lap, args.lap, 1.0, 1.01, 1.02) if args.lap else lap3d(args.lap2d, args.lap2d, 1, 1.0, 1.01, 1.02)
         op = SparseSymmetricMatrix(A)
         print('lap3d setup %.1f s, nnz=%d' % (time.time() - t0, A.nnz))
         nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
