@@ -81,60 +81,64 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
   const R *Xr = reinterpret_cast<const R *>(a.X);
   const R *Yr = reinterpret_cast<const R *>(a.Y);
 
-  struct alignas(16) U16 { R v[RPU]; };
-  U16 regs[UPT];
+  typedef R vec_t __attribute__((ext_vector_type(RPU)));   // 16 bytes: one global_load_dwordx4
+  vec_t regs[UPT];
+
+  // Thread t handles the 16-byte piece k = t % UPC of column (t / UPC) + q * CPQ for q = 0, 1, ...:
+  // the first UY pieces belong to the Y panel (none when the panel is shared with X), the rest to
+  // the X panel.  Columns past the window are clamped to a valid one: they only feed Gram
+  // entries that are never written out, so no zero fill is needed.
+  constexpr int CPQ = 256 / UPC;                 // columns covered by one pass of the 256 threads
+  constexpr int UYQ = CY / CPQ, UXQ = CX / CPQ;  // passes over the Y / X panel
+  static_assert(256 % UPC == 0 && CY % CPQ == 0 && CX % CPQ == 0, "panel / thread mapping");
+  const int tcol = tid / UPC, tk = tid % UPC;
+  const int uy = same_panel ? 0 : UYQ;           // wave-uniform
+
+  auto piece_ptr = [&](int q, int64_t row0) -> const R * {
+    const bool isY = q < uy;
+    int gcol = (isY ? cy0 + q * CPQ : cx0 + (q - uy) * CPQ) + tcol;
+    const int mcols = isY ? a.my : a.mx;
+    gcol = gcol < mcols ? gcol : mcols - 1;
+    return (isY ? Yr : Xr) + ((int64_t)gcol * (isY ? a.ldy : a.ldx) + row0) * NC + tk * RPU;
+  };
 
   auto load_chunk = [&](int64_t chunk) {
     const int64_t row0 = chunk * ROWS;
+    const bool full = ALIGNED && (row0 + ROWS <= a.n);          // wave-uniform
+    if (full) {
 #pragma unroll
-    for (int q = 0; q < UPT; ++q) {
-      const int u = tid + q * 256;
-      U16 val;
+      for (int q = 0; q < UPT; ++q)
+        if (q < uy + UXQ) regs[q] = *reinterpret_cast<const vec_t *>(piece_ptr(q, row0));
+    } else {                                                     // last chunk / unaligned layout
+      const int64_t rend = (a.n - row0) * NC - (int64_t)tk * RPU;   // valid reals from this piece on
 #pragma unroll
-      for (int e = 0; e < RPU; ++e) val.v[e] = (R)0;
-      if (u < nunits) {
-        const bool isY = u < units_y;
-        const int uu = isY ? u : u - units_y;
-        const int col = uu / UPC, k = uu % UPC;
-        const int gcol = (isY ? cy0 : cx0) + col;
-        const int mcols = isY ? a.my : a.mx;
-        const int64_t ld = isY ? a.ldy : a.ldx;
-        const R *base = isY ? Yr : Xr;
-        // real offset inside the column of the first real of this unit
-        const int64_t roff = row0 * NC + (int64_t)k * RPU;
-        const int64_t rend = a.n * NC;             // reals in a column
-        if (gcol < mcols && roff < rend) {
-          const R *p = base + ((int64_t)gcol * ld) * NC + roff;
-          if (ALIGNED && roff + RPU <= rend) {
-            val = *reinterpret_cast<const U16 *>(p);
-          } else {
+      for (int q = 0; q < UPT; ++q) {
+        if (q < uy + UXQ) {
+          const R *p = piece_ptr(q, row0);
+          vec_t val;
 #pragma unroll
-            for (int e = 0; e < RPU; ++e)
-              if (roff + e < rend) val.v[e] = p[e];
-          }
+          for (int e = 0; e < RPU; ++e) val[e] = (e < rend) ? p[e] : (R)0;
+          regs[q] = val;
         }
       }
-      regs[q] = val;
     }
   };
 
   auto store_chunk = [&]() {
 #pragma unroll
     for (int q = 0; q < UPT; ++q) {
-      const int u = tid + q * 256;
-      if (u < nunits) {
-        const bool isY = u < units_y;
-        const int uu = isY ? u : u - units_y;
-        const int col = uu / UPC, k = uu % UPC;
+      if (q < uy + UXQ) {
+        const bool isY = q < uy;
+        const int col = (isY ? q : q - uy) * CPQ + tcol, k = tk;
         R *dst = isY ? ldsY : ldsX;
         if constexpr (!CPLX) {
           R *d = dst + col * S + k * RPU;
           if constexpr (sizeof(R) == 8) {
-            *reinterpret_cast<U16 *>(d) = regs[q];       // ds_write_b128 (S*8 % 16 == 0)
+            *reinterpret_cast<vec_t *>(d) = regs[q];     // ds_write_b128 (S*8 % 16 == 0)
           } else {
             typedef float f2 __attribute__((ext_vector_type(2)));
-            f2 lo = {(float)regs[q].v[0], (float)regs[q].v[1]};
-            f2 hi = {(float)regs[q].v[RPU > 2 ? 2 : 0], (float)regs[q].v[RPU > 3 ? 3 : 1]};
+            f2 lo = {(float)regs[q][0], (float)regs[q][1]};
+            f2 hi = {(float)regs[q][RPU > 2 ? 2 : 0], (float)regs[q][RPU > 3 ? 3 : 1]};
             reinterpret_cast<f2 *>(d)[0] = lo;           // 2 x ds_write_b64 (S*4 % 8 == 0)
             reinterpret_cast<f2 *>(d)[1] = hi;
           }
@@ -144,12 +148,12 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
           R *dre = dst + (2 * col) * S + k * CR;
           R *dim = dre + S;
           if constexpr (CR == 1) {
-            dre[0] = regs[q].v[0];
-            dim[0] = regs[q].v[1];
+            dre[0] = regs[q][0];
+            dim[0] = regs[q][1];
           } else {
             typedef float f2 __attribute__((ext_vector_type(2)));
-            f2 re = {(float)regs[q].v[0], (float)regs[q].v[RPU > 2 ? 2 : 0]};
-            f2 im = {(float)regs[q].v[1], (float)regs[q].v[RPU > 3 ? 3 : 1]};
+            f2 re = {(float)regs[q][0], (float)regs[q][RPU > 2 ? 2 : 0]};
+            f2 im = {(float)regs[q][1], (float)regs[q][RPU > 3 ? 3 : 1]};
             *reinterpret_cast<f2 *>(dre) = re;
             *reinterpret_cast<f2 *>(dim) = im;
           }
@@ -185,7 +189,12 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
 #pragma unroll
       for (int i = 0; i < PI; ++i)
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) acc[i][j] = M::run(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < PJ; ++j) {
+          // a panel of a self-Gram is symmetric: only the tiles on and above its diagonal are
+          // computed, gram_finalize mirrors the rest
+          if (same_panel && i > j) continue;
+          acc[i][j] = M::run(fa[i], fb[j], acc[i][j]);
+        }
     }
   }
 
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
 // result; complex outputs recombine conj(y)*x = (RR + II) + i (RI - IR).
 template <int DT>
 __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int nbx, int npj, int VY, int VX, int my,
-                                                     int mx, void *out_) {
+                                                     int mx, void *out_, int same) {
   using T = typename DType<DT>::T;
   using R = typename DType<DT>::R;
   constexpr bool CPLX = DType<DT>::cplx;
@@ -233,8 +242,11 @@ __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int 
   double t[NCOMP];
 #pragma unroll
   for (int comp = 0; comp < NCOMP; ++comp) {
-    const int vi = CPLX ? 2 * i + (comp >> 1) : i;     // comp: 0 RR, 1 RI, 2 IR, 3 II
-    const int vj = CPLX ? 2 * j + (comp & 1) : j;
+    int vi = CPLX ? 2 * i + (comp >> 1) : i;           // comp: 0 RR, 1 RI, 2 IR, 3 II
+    int vj = CPLX ? 2 * j + (comp & 1) : j;
+    // self-Gram: diagonal panels hold only the 16 x 16 tiles on and above their diagonal; the
+    // real-view Gram matrix is symmetric, so the mirrored entry supplies the rest
+    if (same && vi / VY == vj / VX && (vi % VY) / 16 > (vj % VX) / 16) { const int t_ = vi; vi = vj; vj = t_; }
     const int panel = (vi / VY) * npj + (vj / VX);
     const R *p = partials + ((int64_t)panel * slab + (vi % VY) * VX + (vj % VX)) * nbx;
     double s = 0.0;
@@ -294,7 +306,7 @@ static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, vo
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
   hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nbx, npj, VY,
-                     VX, (int)my, (int)mx, d_out);
+                     VX, (int)my, (int)mx, d_out, a.same);
   RLH_HIP(hipGetLastError());
   return 0;
 }
