@@ -15,6 +15,8 @@
 // Replaces: cublas?gemm(ConjTrans, NoTrans) + cudaMalloc/cudaMemcpy/cudaFree per call
 // (raleigh/algebra/dense_cublas.py:245-269), m blocking cublas?dot calls
 // (dense_cublas.py:233-243) and gemmBatched (dense_cublas.py:175-221).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace rlh {
@@ -278,6 +280,8 @@ static int gram_blocks_per_cu() {
         nb < 1)
       nb = 1;
     cached = nb > 8 ? 8 : nb;
+    const char *e = getenv("RLH_GRAM_WG_PER_CU");          // tunable cap on resident workgroups
+    if (e && *e && atoi(e) > 0 && atoi(e) < cached) cached = atoi(e);
   }
   return cached;
 }

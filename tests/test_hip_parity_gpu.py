@@ -244,3 +244,36 @@ def test_empty_and_degenerate():
     assert np.all(x.data() == 1)
     z = Vectors(0, 2, data_type=np.float32)
     assert z.dot(z).shape == (2, 2) and np.all(z.dot(z) == 0)
+
+
+def test_more_than_2_31_elements_in_a_block():
+    """The reference passes sizes as c_int and overflows at n*m >= 2^31 (cuda_wrap.py:143,
+    dense_cublas.py:142); here every size is 64-bit.  fp32 block of 67 200 000 x 33 = 2.2e9
+    elements (8.9 GB): exact integer sums located past the 2^31-element mark."""
+    from raleigh_amd.algebra.hip import Vectors
+    n, m = 67_200_000, 33
+    assert n * m > 2 ** 31
+    X = Vectors(n, m, data_type=np.float32)              # zero-filled on the device
+    col = np.zeros((1, n), dtype=np.float32)
+    col[0, -1000:] = 1.0
+    col[0, :7] = 2.0
+    for j in (0, 32):                                     # first and last vector
+        X.select(1, j)
+        X.fill(col)
+    X.select(m)
+    d = X.dots(X)
+    expect = np.zeros(m, dtype=np.float32)
+    expect[[0, 32]] = 1000.0 + 7 * 4.0
+    assert np.array_equal(d, expect)
+    g = X.dot(X)
+    assert g[32, 0] == 1028.0 and g[0, 32] == 1028.0 and g[32, 32] == 1028.0 and g[1, 1] == 0.0
+    W = Vectors(n, 2, data_type=np.float32)
+    q = np.zeros((m, 2), dtype=np.float32)
+    q[32, 0], q[0, 1], q[32, 1] = 3.0, 1.0, 1.0
+    X.multiply(q, W)                                      # W0 = 3 x32, W1 = x0 + x32
+    assert np.array_equal(W.dots(W), np.array([9 * 1028.0, 4 * 1028.0], dtype=np.float32))
+    X.select(1, 32)
+    W.select(1, 0)
+    X.copy(W)
+    W.add(X, -1.0)
+    assert W.dots(W)[0] == 0.0
