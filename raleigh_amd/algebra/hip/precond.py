@@ -1,0 +1,54 @@
+"""Device-resident polynomial preconditioner.
+
+The reference's preconditioner is MKL's ILUT applied on the host with two triangular solves
+per vector (raleigh/algebra/mkl_wrap.py:279-347); a device counterpart of the same
+factorisation is future work.  This class offers what the survey lists as the alternative: a
+fixed polynomial p(A) ~ A^-1 (Chebyshev semi-iteration on [lo, hi]) built only from the
+operator's ``apply`` and the block operations, so every block stays in HBM.  p(A) is
+symmetric positive definite for a positive definite A (0 < 1 - r(x) on (0, hi], r the
+Chebyshev residual polynomial), as the solver requires of a preconditioner
+(raleigh/interfaces/partial_hevp.py:41-49).  It changes iteration counts relative to ILU, so
+runs using it are reported separately from the reference's.
+"""
+
+import numpy as np
+
+
+def gershgorin_upper_bound(matrix):
+    """max_i sum_j |a_ij| >= lambda_max for a symmetric / Hermitian matrix (SciPy sparse)."""
+    a = abs(matrix)
+    return float(np.max(np.asarray(a.sum(axis=1)).ravel()))
+
+
+class ChebyshevPreconditioner:
+
+    def __init__(self, op, hi, ratio=50.0, degree=6):
+        """op: operator with apply(x, y); hi: upper bound of its spectrum; the polynomial
+        approximates 1/x on [hi / ratio, hi]; degree: number of operator applications."""
+        if degree < 1:
+            raise ValueError('degree must be at least 1')
+        self._op = op
+        self._lo, self._hi = float(hi) / float(ratio), float(hi)
+        self._degree = int(degree)
+        self._work = None
+
+    def apply(self, x, y):
+        m = x.nvec()
+        if self._work is None or self._work[0].nvec() < m or self._work[0].dimension() != x.dimension():
+            self._work = [x.new_vectors(m) for _ in range(3)]
+        r, d, t = self._work
+        for v in (r, d, t):
+            v.select(m)
+        theta, delta = 0.5 * (self._hi + self._lo), 0.5 * (self._hi - self._lo)
+        sigma1 = theta / delta
+        rho = 1.0 / sigma1
+        x.copy(r)                                   # r = x - A*0
+        d.lincomb(1.0 / theta, x, 0.0, x)           # d = r / theta
+        d.copy(y)                                   # y = d
+        for _ in range(self._degree - 1):
+            self._op.apply(d, t)
+            r.add(t, -1.0)                          # r -= A d
+            rho_new = 1.0 / (2.0 * sigma1 - rho)
+            d.lincomb(rho_new * rho, d, 2.0 * rho_new / delta, r)
+            y.add(d, 1.0)
+            rho = rho_new

@@ -11,6 +11,8 @@ ap.add_argument('--block', type=int, default=-1)
 ap.add_argument('--maxit', type=int, default=3000)
 ap.add_argument('--verb', type=int, default=-1)
 ap.add_argument('--profile', action='store_true')
+ap.add_argument('--cheb', type=int, default=0, help='degree of the device Chebyshev preconditioner (0: none)')
+ap.add_argument('--ratio', type=float, default=100.0)
 a = ap.parse_args()
 from raleigh_amd.interfaces import partial_hevp
 from raleigh_amd.core.solver import Options
@@ -25,7 +27,12 @@ t0 = time.time()
 if a.profile:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
-lmd, x, status = partial_hevp(A, T=True, which=a.k, tol=a.tol, verb=a.verb, opt=opt)
+T = True
+if a.cheb > 0:
+    from raleigh_amd.algebra.hip import SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
+    T = ChebyshevPreconditioner(SparseSymmetricMatrix(A), gershgorin_upper_bound(A), ratio=a.ratio, degree=a.cheb)
+lmd, x, status = partial_hevp(A, T=T, which=a.k, tol=a.tol, verb=a.verb, opt=opt)
 if a.profile:
     pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(35)
 el = time.time() - t0
