@@ -59,6 +59,8 @@ SIGNATURES = {
     'rlh_csr_info': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                      ctypes.POINTER(_i64)],
     'rlh_spmm': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64],
+    'rlh_spmm_cheb': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double,
+                      ctypes.c_double],
     'rlh_dense_apply': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64],
     'rlh_timer_start': [],
     'rlh_timer_stop': [ctypes.POINTER(ctypes.c_float)],

@@ -304,39 +304,49 @@ class ShardedSparseMatrix:
             self._bufs[key] = (c.buffer(ns * m * es), c.buffer(nr * m * es), c.buffer(nr * m * es))
         return self._bufs[key]
 
-    def apply(self, x, y):
+    def _exchange_halo(self, x):
+        """Brings the off-shard rows of x referenced by this rank's rows into one halo block;
+        returns (device pointer, leading dimension) or (None, 0) when nothing is off-shard."""
         c, L = self._comm, _lib.lib()
+        m = x.nvec()
+        code, es = x._code, x._es
+        if not (self._n_halo > 0 or self._send):
+            return None, 0
+        sendbuf, recvbuf, halo = self._buffers(m, es)
+        ops, soff, roff = [], 0, 0
+        for p, didx, cnt in self._send:                   # pack the rows each peer needs
+            _lib.check(L.rlh_gather_rows(code, cnt, didx.data_ptr(), m, x.data_ptr(), x.ld(),
+                                         sendbuf.data_ptr() + soff, cnt))
+            ops.append(c.dist.P2POp(c.dist.isend, sendbuf[soff:soff + cnt * m * es], p, group=c.group))
+            soff += cnt * m * es
+        for p, hs, cnt in self._recv:
+            ops.append(c.dist.P2POp(c.dist.irecv, recvbuf[roff:roff + cnt * m * es], p, group=c.group))
+            roff += cnt * m * es
+        if ops:
+            for w in c.dist.batch_isend_irecv(ops):
+                w.wait()
+        roff = 0
+        for p, hs, cnt in self._recv:                     # peer blocks (ld = cnt) -> one halo block (ld = n_halo)
+            _lib.check(L.rlh_copy2d(halo.data_ptr() + hs * es, self._n_halo * es,
+                                    recvbuf.data_ptr() + roff, cnt * es, cnt * es, m, 2))
+            roff += cnt * m * es
+        if self._n_halo > 0:
+            return halo.data_ptr(), self._n_halo
+        return None, 0
+
+    def apply(self, x, y):
         m = x.nvec()
         if m != y.nvec():
             raise ValueError('Numbers of input and output vectors differ')
         if x.dimension() != self._n or y.dimension() != self._n:
             raise ValueError('Matrix and vectors dimensions incompatible')
-        code, es = x._code, x._es
-        halo_ptr, ldh = None, 0
-        if self._n_halo > 0 or self._send:
-            sendbuf, recvbuf, halo = self._buffers(m, es)
-            ops, soff, roff = [], 0, 0
-            tt = c.torch
-            for p, didx, cnt in self._send:                   # pack the rows each peer needs
-                _lib.check(L.rlh_gather_rows(code, cnt, didx.data_ptr(), m, x.data_ptr(), x.ld(),
-                                             sendbuf.data_ptr() + soff, cnt))
-                ops.append(c.dist.P2POp(c.dist.isend, sendbuf[soff:soff + cnt * m * es], p, group=c.group))
-                soff += cnt * m * es
-            for p, hs, cnt in self._recv:
-                ops.append(c.dist.P2POp(c.dist.irecv, recvbuf[roff:roff + cnt * m * es], p, group=c.group))
-                roff += cnt * m * es
-            if ops:
-                for w in c.dist.batch_isend_irecv(ops):
-                    w.wait()
-            roff = 0
-            for p, hs, cnt in self._recv:                     # peer blocks (ld = cnt) -> one halo block (ld = n_halo)
-                _lib.check(L.rlh_copy2d(halo.data_ptr() + hs * es, self._n_halo * es,
-                                        recvbuf.data_ptr() + roff, cnt * es, cnt * es, m, 2))
-                roff += cnt * m * es
-            if self._n_halo > 0:
-                halo_ptr, ldh = halo.data_ptr(), self._n_halo
+        halo_ptr, ldh = self._exchange_halo(x)
         self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh)
 
+    def cheb_step(self, d, r, dn, y, alpha, beta):
+        """Fused step of the Chebyshev semi-iteration on row-sharded blocks (one halo exchange of d)."""
+        halo_ptr, ldh = self._exchange_halo(d)
+        self._op.cheb_step_ptr(d.nvec(), d, r, dn, y, alpha, beta, halo_ptr, ldh)
 
 class ShardedDenseMatrix:
     """Dense operator whose ROWS are distributed over the ranks (BASELINE configs 2/4: the PCA

@@ -45,10 +45,16 @@ class ChebyshevPreconditioner:
         x.copy(r)                                   # r = x - A*0
         d.lincomb(1.0 / theta, x, 0.0, x)           # d = r / theta
         d.copy(y)                                   # y = d
+        fused = hasattr(self._op, 'cheb_step')
         for _ in range(self._degree - 1):
-            self._op.apply(d, t)
-            r.add(t, -1.0)                          # r -= A d
             rho_new = 1.0 / (2.0 * sigma1 - rho)
-            d.lincomb(rho_new * rho, d, 2.0 * rho_new / delta, r)
-            y.add(d, 1.0)
+            if fused:       # r -= A d; dn = a d + b r; y += dn -- one pass, dn in the spare block
+                self._op.cheb_step(d, r, t, y, rho_new * rho, 2.0 * rho_new / delta)
+                d, t = t, d
+            else:
+                self._op.apply(d, t)
+                r.add(t, -1.0)                      # r -= A d
+                d.lincomb(rho_new * rho, d, 2.0 * rho_new / delta, r)
+                y.add(d, 1.0)
             rho = rho_new
+        self._work = [r, d, t]

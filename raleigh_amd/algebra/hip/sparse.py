@@ -67,6 +67,12 @@ class CsrOperator:
     def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0):
         _lib.check(_lib.lib().rlh_spmm(self._h, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
 
+    def cheb_step_ptr(self, m, d, r, dn, y, alpha, beta, halo_ptr=None, ldh=0):
+        """r -= A d; dn = alpha d + beta r; y += dn in one pass (d, r, dn, y: Vectors windows)."""
+        _lib.check(_lib.lib().rlh_spmm_cheb(self._h, m, d.data_ptr(), d.ld(), self._n_own, halo_ptr, ldh,
+                                            r.data_ptr(), r.ld(), dn.data_ptr(), dn.ld(), y.data_ptr(), y.ld(),
+                                            float(alpha), float(beta)))
+
 
 class SparseSymmetricMatrix:
 
@@ -99,6 +105,10 @@ class SparseSymmetricMatrix:
         if x.nvec() != y.nvec():
             raise ValueError('Numbers of input and output vectors differ')
         self.__op.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
+
+    def cheb_step(self, d, r, dn, y, alpha, beta):
+        """Fused step of the Chebyshev semi-iteration: r -= A d; dn = alpha d + beta r; y += dn."""
+        self.__op.cheb_step_ptr(d.nvec(), d, r, dn, y, alpha, beta)
 
 
 class Operator:

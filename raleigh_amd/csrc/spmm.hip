@@ -60,14 +60,33 @@ __device__ __forceinline__ void nt_store(c64 *p, c64 v) {
 //    the SAME slice (tiles_per_block of them), which keeps the set of rows in flight per XCD --
 //    and with it the L2 footprint of the gathered X lines -- small; the matrix entries of the
 //    slice are fetched once per workgroup through L1.
-template <typename T, int JT, int TT>
+// Fused Chebyshev step (CHEB): with t = A d the row's results update r -= t, dn = alpha d + beta r,
+// y += dn in the same pass (device polynomial preconditioner); dn must not alias d, which other
+// rows are still gathering.
+template <typename T>
+struct ChebArgs {
+  T *R; int64_t ldr;
+  T *Dn; int64_t lddn;
+  double alpha, beta;
+};
+
+__device__ __forceinline__ float  scale_of(double s, float v)  { return (float)s * v; }
+__device__ __forceinline__ double scale_of(double s, double v) { return s * v; }
+__device__ __forceinline__ c32 scale_of(double s, c32 v) { return c32{(float)s * v.re, (float)s * v.im}; }
+__device__ __forceinline__ c64 scale_of(double s, c64 v) { return c64{s * v.re, s * v.im}; }
+__device__ __forceinline__ float  sub_of(float a, float b)   { return a - b; }
+__device__ __forceinline__ double sub_of(double a, double b) { return a - b; }
+__device__ __forceinline__ c32 sub_of(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ c64 sub_of(c64 a, c64 b) { return c64{a.re - b.re, a.im - b.im}; }
+
+template <typename T, int JT, int TT, bool CHEB>
 __global__ __launch_bounds__(256, (JT * TT >= 64 ? 1 : 2)) void sell_spmm_kernel(const int64_t *__restrict__ slice_ptr,
                                                         const int32_t *__restrict__ cols,
                                                         const T *__restrict__ vals, int64_t n_rows,
                                                         int64_t n_slices, const T *__restrict__ X, int64_t ldx,
                                                         int64_t n_own, const T *__restrict__ H, int64_t ldh,
                                                         T *__restrict__ Y, int64_t ldy, int m, int chunk,
-                                                        int ntiles, int tiles_per_block) {
+                                                        int ntiles, int tiles_per_block, ChebArgs<T> cheb) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int xcd = blockIdx.x & 7;                                  // gridDim.x is a multiple of 8
@@ -126,9 +145,24 @@ __global__ __launch_bounds__(256, (JT * TT >= 64 ? 1 : 2)) void sell_spmm_kernel
           for (int j = 0; j < JT; ++j) fma_acc(acc[j], v[u], xv[u][j]);
       }
       if (row < n_rows) {
+        if constexpr (!CHEB) {
 #pragma unroll
-        for (int j = 0; j < JT; ++j)
-          if (j < jv) nt_store(Yp + row + (int64_t)j * ldy, acc[j]);
+          for (int j = 0; j < JT; ++j)
+            if (j < jv) nt_store(Yp + row + (int64_t)j * ldy, acc[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < JT; ++j)
+            if (j < jv) {
+              const int64_t jc = j0 + j;
+              T *rp = cheb.R + row + jc * cheb.ldr;
+              const T rr = sub_of(*rp, acc[j]);                               // r -= A d
+              const T dn = add_of(scale_of(cheb.alpha, Xp[row + (int64_t)j * ldx]), scale_of(cheb.beta, rr));
+              *rp = rr;
+              cheb.Dn[row + jc * cheb.lddn] = dn;                             // dn = alpha d + beta r
+              T *yp = Yp + row + (int64_t)j * ldy;
+              *yp = add_of(*yp, dn);                                          // y += dn
+            }
+        }
       }
     }
   }
@@ -141,12 +175,12 @@ static int env_int(const char *name, int dflt) {
 
 template <typename T, int JT, int TT>
 static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
-                       T *Y, int64_t ldy) {
+                       T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
   Context &c = ctx();
   static int per_cu = 0;
   if (per_cu == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sell_spmm_kernel<T, JT, TT>, 256, 0) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sell_spmm_kernel<T, JT, TT, false>, 256, 0) != hipSuccess || nb < 1)
       nb = 1;
     per_cu = nb > 8 ? 8 : nb;
     const int cap = env_int("RLH_SPMM_WG_PER_CU", 2);       // 0: as many as fit (tunable; 2 measured best)
@@ -162,34 +196,42 @@ static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, i
   const int64_t need = ((h->n_slices + slices_per_block - 1) / slices_per_block + 7) / 8 * 8;
   if (nb > need) nb = need;
   nb = (nb + 7) / 8 * 8;
-  hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr, h->cols,
-                     (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
-                     chunk < 1 ? 1 : chunk, ntiles, tiles_per_block);
+  if (cheb)
+    hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT, true>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr,
+                       h->cols, (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                       chunk < 1 ? 1 : chunk, ntiles, tiles_per_block, *cheb);
+  else
+    hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT, false>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr,
+                       h->cols, (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                       chunk < 1 ? 1 : chunk, ntiles, tiles_per_block, ChebArgs<T>{});
   RLH_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T, int JT>
 static int launch_spmm(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
-                       T *Y, int64_t ldy) {
+                       T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
   static const int tt = env_int("RLH_SPMM_TT", 1);             // entries per register group (tunable)
-  if (tt >= 8) return launch_spmm_t<T, JT, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  if (tt >= 4) return launch_spmm_t<T, JT, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  return launch_spmm_t<T, JT, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  if (tt >= 8) return launch_spmm_t<T, JT, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if (tt >= 4) return launch_spmm_t<T, JT, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  return launch_spmm_t<T, JT, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 
 template <int DT>
 static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, int64_t n_own, const void *H_,
-                     int64_t ldh, void *Y_, int64_t ldy) {
+                     int64_t ldh, void *Y_, int64_t ldy, void *R_ = nullptr, int64_t ldr = 0, void *Dn_ = nullptr,
+                     int64_t lddn = 0, double alpha = 0.0, double beta = 0.0) {
   using T = typename DType<DT>::T;
   constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
   const T *X = (const T *)X_, *H = (const T *)H_;
   T *Y = (T *)Y_;
+  ChebArgs<T> cargs{(T *)R_, ldr, (T *)Dn_, lddn, alpha, beta};
+  const ChebArgs<T> *cheb = R_ ? &cargs : nullptr;
   static const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
-  if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  if (m <= 16 || JTMAX == 16 || jt_cap <= 16) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-  return launch_spmm<T, (JTMAX == 32 ? 32 : 16)>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if (m <= 16 || JTMAX == 16 || jt_cap <= 16) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  return launch_spmm<T, (JTMAX == 32 ? 32 : 16)>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 
 template <typename T>
@@ -338,6 +380,28 @@ int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own, 
     case RLH_D: return spmm_impl<RLH_D>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
     case RLH_C: return spmm_impl<RLH_C>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
     case RLH_Z: return spmm_impl<RLH_Z>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+  }
+  return 1;
+}
+
+int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *D, int64_t ldd, int64_t n_own, const void *H, int64_t ldh,
+                  void *R, int64_t ldr, void *Dn, int64_t lddn, void *Y, int64_t ldy, double alpha, double beta) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(h != nullptr, "rlh_spmm_cheb: null handle");
+  RLH_REQUIRE(m >= 0, "rlh_spmm_cheb: negative block size");
+  if (m == 0 || h->n_rows == 0) return 0;
+  RLH_REQUIRE(D && R && Dn && Y, "rlh_spmm_cheb: null block pointer");
+  RLH_REQUIRE(h->n_rows <= n_own && n_own <= h->n_cols, "rlh_spmm_cheb: the operator block must be square in its own rows");
+  RLH_REQUIRE(n_own == h->n_cols || H, "rlh_spmm_cheb: halo block missing for columns >= n_own");
+  RLH_REQUIRE(ldd >= n_own && ldr >= h->n_rows && lddn >= h->n_rows && ldy >= h->n_rows &&
+                  (!H || ldh >= h->n_cols - n_own),
+              "rlh_spmm_cheb: leading dimension smaller than the operator size");
+  RLH_REQUIRE(Dn != D && Dn != R && Dn != Y && D != R && D != Y && R != Y, "rlh_spmm_cheb: the four blocks must be distinct");
+  switch (h->dtype) {
+    case RLH_S: return spmm_impl<RLH_S>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
+    case RLH_D: return spmm_impl<RLH_D>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
+    case RLH_C: return spmm_impl<RLH_C>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
+    case RLH_Z: return spmm_impl<RLH_Z>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
   }
   return 1;
 }

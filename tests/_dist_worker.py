@@ -94,6 +94,17 @@ def main():
     assert x.shape == (n, 4)
     r = A @ x - x * lmd
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
+    # the same with the device polynomial preconditioner (fused Chebyshev step + halo exchange)
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 300
+    T = ChebyshevPreconditioner(op, gershgorin_upper_bound(A), ratio=100, degree=6)
+    lmd2, x2, status = partial_hevp(None, T=T, which=4, tol=1e-8, verb=-1, opt=opt, vectors=mk, operator=op)
+    assert status == 0, status
+    assert np.max(np.abs(lmd2[:4] - ana) / ana) < 1e-10
+    assert fake_lib_calls().get('spmm_cheb', 0) > 10
+
     # row-sharded dense operator and PCA (BASELINE config 4 layout): same answer as one rank
     from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix
     from raleigh_amd.algebra.hip import Vectors
@@ -133,6 +144,11 @@ def main():
     if rank == 0:
         print('DIST_OK world=%d' % size)
     dist.destroy_process_group()
+
+
+def fake_lib_calls():
+    from raleigh_amd import _lib
+    return _lib.library().calls
 
 
 def off_len(n, size, rank):

@@ -228,3 +228,23 @@ def test_device_chebyshev_preconditioner():
         assert np.max(np.abs(lmd[:6] - ana) / ana) < 1e-10
         iters[name] = partial_hevp.last['iterations']
     assert iters['cheb'] * 3 < iters['none']
+
+
+def test_fused_chebyshev_step_equals_unfused():
+    """rlh_spmm_cheb (r -= A d; dn = a d + b r; y += dn) against the same step from apply/add/lincomb."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from oracle.sparse import lap3d
+    A = lap3d(9, 8, 7, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    d0, r0, y0 = (rng.standard_normal((5, n)) for _ in range(3))
+    op = SparseSymmetricMatrix(A)
+    d, r, y, dn = Vectors(d0.copy()), Vectors(r0.copy()), Vectors(y0.copy()), Vectors(n, 5)
+    op.cheb_step(d, r, dn, y, 0.3, -1.7)
+    t = (A @ d0.T).T
+    r1 = r0 - t
+    dn1 = 0.3 * d0 - 1.7 * r1
+    assert np.allclose(r.data(), r1, rtol=1e-13, atol=1e-12)
+    assert np.allclose(dn.data(), dn1, rtol=1e-13, atol=1e-12)
+    assert np.allclose(y.data(), y0 + dn1, rtol=1e-13, atol=1e-12)
+    assert np.array_equal(d.data(), d0)

@@ -277,3 +277,27 @@ def test_more_than_2_31_elements_in_a_block():
     X.copy(W)
     W.add(X, -1.0)
     assert W.dots(W)[0] == 0.0
+
+
+@pytest.mark.parametrize('key', ['d', 'z'])
+def test_fused_chebyshev_step(key):
+    """rlh_spmm_cheb: r -= A d; dn = a d + b r; y += dn in one pass, against the oracle."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    A = lap3d(23, 19, 17, 1.0, 1.01, 1.02)
+    if key == 'z':
+        S = sp.diags([np.full(A.shape[0] - 1, 0.3)], [1], shape=A.shape)
+        A = sp.csr_matrix(A.astype(np.complex128) + 1j * S - 1j * S.T)
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    m = 21
+    d0, r0, y0 = (rnd((m, n), key, rng) for _ in range(3))
+    op = SparseSymmetricMatrix(A)
+    d, r, y, dn = Vectors(d0.copy()), Vectors(r0.copy()), Vectors(y0.copy()), Vectors(n, m, data_type=DT[key])
+    op.cheb_step(d, r, dn, y, 0.3, -1.7)
+    t = ops.csr_sym_apply(sp.triu(A, format='csr'), d0)
+    r1 = r0 - t
+    dn1 = 0.3 * d0 - 1.7 * r1
+    assert cases.rel(r.data(), r1) < 1e-13
+    assert cases.rel(dn.data(), dn1) < 1e-13
+    assert cases.rel(y.data(), y0 + dn1) < 1e-13
+    assert np.array_equal(d.data(), d0)
