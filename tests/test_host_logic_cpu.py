@@ -42,8 +42,10 @@ def test_errors(fake):
         Matrix(np.zeros((4, 6))[:, ::2])
     u = Vectors(np.zeros((3, 10)))
     w = Vectors(np.zeros((2, 10)))
+    with pytest.raises(ValueError):        # 3 x 3 coefficients cannot map 3 vectors onto 2
+        u._update(np.zeros((3, 3)), u, w, 1.0, 0)
     with pytest.raises(ValueError):
-        u.multiply(np.zeros((3, 3)), w.new_vectors(2)) if False else u._update(np.zeros((3, 3)), u, w, 1.0, 0)
+        u.combine(np.zeros((3, 2)), w, np.zeros((3, 2)), w.new_vectors(2))
     with pytest.raises(ValueError):
         u.fill(np.zeros((3, 9)))
     with pytest.raises(ValueError):
