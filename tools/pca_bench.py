@@ -10,6 +10,8 @@ ap.add_argument('--N', type=int, default=20000)
 ap.add_argument('--rank', type=int, default=400)
 ap.add_argument('--npc', type=int, default=200)
 ap.add_argument('--gemm-only', action='store_true')
+ap.add_argument('--profile', action='store_true')
+ap.add_argument('--no-check', action='store_true')
 a = ap.parse_args()
 from raleigh_amd import _lib
 from raleigh_amd.algebra.hip import Vectors, Matrix
@@ -43,12 +45,19 @@ print('apply rel err vs fp64 host: %.2e' % (np.linalg.norm(y.data()[:4, :200] - 
 if not a.gemm_only:
     from raleigh_amd.interfaces import pca
     np.random.seed(1)
+    if a.profile:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
     t0 = time.time()
     mean, trans, comps = pca(A, npc=a.npc)
     el = time.time() - t0
+    if a.profile:
+        pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(22)
     sv = np.linalg.norm(trans, axis=0)
     # exact singular values of the shifted matrix: A - e*mean removes the constant left vector
     print('pca npc=%d: %.2f s, iterations %d, operator time %.2f s' % (a.npc, el, pca.last['iterations'], pca.last['operator_time']))
+    if a.no_check:
+        sys.exit(0)
     As = A - A.mean(axis=0, keepdims=True)
     G = (As.T @ As).astype(np.float64) if N <= M else (As @ As.T).astype(np.float64)
     ex = np.sqrt(np.abs(np.linalg.eigvalsh(G)[::-1][:a.npc]))
