@@ -226,14 +226,15 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region
     rng = np.random.default_rng(1 + rank)
-    host = 2 * rng.random((m, nloc)) - 1
     if comm is None:
         mk = lambda: Vectors(nloc, m, data_type=np.float64)
     else:
         mk = lambda: ShardedVectors(n, m, np.float64, comm=comm, offsets=off)
     blocks = [mk() for _ in range(7)]
-    Vectors.fill(blocks[0], host)
-    del host
+    for j in range(m):                            # U(-1, 1), one vector at a time (bounded host memory)
+        blocks[0].select(1, j)
+        Vectors.fill(blocks[0], 2 * rng.random((1, nloc)) - 1)
+    blocks[0].select(m)
     for i, b in enumerate(blocks[1:], 1):         # distinct random-looking blocks from device-side ops
         blocks[0].copy(b, np.roll(np.arange(m), i))
         b.add(blocks[0], 0.37 * i)
