@@ -65,6 +65,9 @@ int rlh_memset(void *dptr, int value, int64_t bytes);            /* async */
 int rlh_h2d(void *dptr, const void *hptr, int64_t bytes);        /* sync  */
 int rlh_d2h(void *hptr, const void *dptr, int64_t bytes);        /* sync  */
 int rlh_d2d(void *dst, const void *src, int64_t bytes);          /* async */
+/* small device result -> host through the library's pinned buffer (one stream synchronisation);
+ * used after an RCCL all-reduce of a Gram / dots result */
+int rlh_fetch(void *hptr, const void *dptr, int64_t bytes);      /* sync  */
 /* rows x width_bytes strided copy, kind: 0 h2d, 1 d2h, 2 d2d
  * (dense_cublas.py:61-68 append(axis=1); padded-ld upload/download). */
 int rlh_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch,

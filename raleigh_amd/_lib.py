@@ -39,6 +39,7 @@ SIGNATURES = {
     'rlh_h2d': [_p, _p, _i64],
     'rlh_d2h': [_p, _p, _i64],
     'rlh_d2d': [_p, _p, _i64],
+    'rlh_fetch': [_p, _p, _i64],
     'rlh_copy2d': [_p, _i64, _p, _i64, _i64, _i64, _int],
     'rlh_gram': [_int, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _p],
     'rlh_dots': [_int, _i64, _i64, _p, _i64, _p, _i64, _p, _p],

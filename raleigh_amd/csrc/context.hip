@@ -224,6 +224,14 @@ int rlh_d2h(void *hptr, const void *dptr, int64_t bytes) {
   return 0;
 }
 
+int rlh_fetch(void *hptr, const void *dptr, int64_t bytes) {
+  if (int rc = require_ready()) return rc;
+  if (bytes <= 0) return 0;
+  RLH_REQUIRE(hptr && dptr, "rlh_fetch: null pointer");
+  if (int rc = ensure_result((size_t)bytes)) return rc;
+  return fetch_result(hptr, dptr, (size_t)bytes);
+}
+
 int rlh_d2d(void *dst, const void *src, int64_t bytes) {
   if (int rc = require_ready()) return rc;
   if (bytes <= 0) return 0;

@@ -115,6 +115,7 @@ class FakeLib:
 
     rlh_d2h = rlh_h2d
     rlh_d2d = rlh_h2d
+    rlh_fetch = rlh_h2d
 
     def rlh_copy2d(self, dst, dpitch, src, spitch, width, rows, kind):
         d, s = _addr(dst), _addr(src)
