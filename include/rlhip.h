@@ -136,6 +136,10 @@ int rlh_copy_cols(int dtype, int64_t n, int64_t m, const int64_t *ind,
  * mode 1: X[:,i] *= s[i]; mode 0: X[:,i] /= s[i] unless s[i] == 0. */
 int rlh_scale_cols(int dtype, int64_t n, int64_t m, const double *s, int mode,
                    void *X, int64_t ldx);
+/* precision conversion Y = (dst type) X between s<->d or c<->z blocks (mixed-precision
+ * preconditioning; not in the reference) */
+int rlh_convert(int src_dtype, int dst_dtype, int64_t n, int64_t m, const void *X,
+                int64_t ldx, void *Y, int64_t ldy);
 /* in-place complex conjugate (dense_cublas.py:503-511); no-op for real */
 int rlh_conj(int dtype, int64_t n, int64_t m, void *X, int64_t ldx);
 

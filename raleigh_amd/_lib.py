@@ -53,6 +53,7 @@ SIGNATURES = {
     'rlh_copy': [_int, _i64, _i64, _p, _i64, _p, _i64],
     'rlh_copy_cols': [_int, _i64, _i64, _p, _p, _i64, _p, _i64],
     'rlh_scale_cols': [_int, _i64, _i64, _p, _int, _p, _i64],
+    'rlh_convert': [_int, _int, _i64, _i64, _p, _i64, _p, _i64],
     'rlh_conj': [_int, _i64, _i64, _p, _i64],
     'rlh_gather_rows': [_int, _i64, _p, _i64, _p, _i64, _p, _i64],
     'rlh_csr_create': [ctypes.POINTER(_p), _int, _i64, _i64, _p, _p, _p],

@@ -140,13 +140,13 @@ class ShardedVectors(Vectors):
     def offsets(self):
         return self._offsets
 
-    def new_vectors(self, arg=0, dim=None):
+    def new_vectors(self, arg=0, dim=None, data_type=None):
         if isinstance(arg, np.ndarray):
             return ShardedVectors(arg, comm=self._comm)
+        dt = self.data_type() if data_type is None else data_type
         if dim is not None and dim != self._gdim:
-            return ShardedVectors(dim, int(arg), self.data_type(), comm=self._comm)
-        return ShardedVectors(self._gdim, int(arg), self.data_type(), comm=self._comm,
-                              offsets=self._offsets)
+            return ShardedVectors(dim, int(arg), dt, comm=self._comm)
+        return ShardedVectors(self._gdim, int(arg), dt, comm=self._comm, offsets=self._offsets)
 
     def clone(self):
         return ShardedVectors(self)

@@ -22,12 +22,18 @@ def gershgorin_upper_bound(matrix):
 
 class ChebyshevPreconditioner:
 
-    def __init__(self, op, hi, ratio=50.0, degree=6):
+    def __init__(self, op, hi, ratio=50.0, degree=6, low_precision_op=None):
         """op: operator with apply(x, y); hi: upper bound of its spectrum; the polynomial
-        approximates 1/x on [hi / ratio, hi]; degree: number of operator applications."""
+        approximates 1/x on [hi / ratio, hi]; degree: number of operator applications.
+
+        low_precision_op: the same operator in float32 / complex64.  When given, the polynomial
+        is evaluated in that precision (half the bytes through the gather-bound SpMM); the input
+        and the result are converted on the device.  A preconditioner only has to be a fixed,
+        (nearly) symmetric positive definite approximation of A^-1, which single precision is."""
         if degree < 1:
             raise ValueError('degree must be at least 1')
-        self._op = op
+        self._op = op if low_precision_op is None else low_precision_op
+        self._low = low_precision_op is not None
         self._lo, self._hi = float(hi) / float(ratio), float(hi)
         self._degree = int(degree)
         self._work = None
@@ -35,26 +41,36 @@ class ChebyshevPreconditioner:
     def apply(self, x, y):
         m = x.nvec()
         if self._work is None or self._work[0].nvec() < m or self._work[0].dimension() != x.dimension():
-            self._work = [x.new_vectors(m) for _ in range(3)]
-        r, d, t = self._work
-        for v in (r, d, t):
+            dt = None
+            if self._low:
+                dt = np.complex64 if x.is_complex() else np.float32
+            self._work = [x.new_vectors(m, data_type=dt) for _ in range(5 if self._low else 3)]
+        for v in self._work:
             v.select(m)
+        r, d, t = self._work[:3]
+        if self._low:
+            xin, yout = self._work[3], self._work[4]
+            x.convert_to(xin)
+        else:
+            xin, yout = x, y
         theta, delta = 0.5 * (self._hi + self._lo), 0.5 * (self._hi - self._lo)
         sigma1 = theta / delta
         rho = 1.0 / sigma1
-        x.copy(r)                                   # r = x - A*0
-        d.lincomb(1.0 / theta, x, 0.0, x)           # d = r / theta
-        d.copy(y)                                   # y = d
+        xin.copy(r)                                 # r = x - A*0
+        d.lincomb(1.0 / theta, xin, 0.0, xin)       # d = r / theta
+        d.copy(yout)                                # y = d
         fused = hasattr(self._op, 'cheb_step')
         for _ in range(self._degree - 1):
             rho_new = 1.0 / (2.0 * sigma1 - rho)
             if fused:       # r -= A d; dn = a d + b r; y += dn -- one pass, dn in the spare block
-                self._op.cheb_step(d, r, t, y, rho_new * rho, 2.0 * rho_new / delta)
+                self._op.cheb_step(d, r, t, yout, rho_new * rho, 2.0 * rho_new / delta)
                 d, t = t, d
             else:
                 self._op.apply(d, t)
                 r.add(t, -1.0)                      # r -= A d
                 d.lincomb(rho_new * rho, d, 2.0 * rho_new / delta, r)
-                y.add(d, 1.0)
+                yout.add(d, 1.0)
             rho = rho_new
-        self._work = [r, d, t]
+        self._work[:3] = [r, d, t]
+        if self._low:
+            yout.convert_to(y)

@@ -111,9 +111,11 @@ class Vectors:
         return self._buf
 
     # ------------------------------------------------------------ solver-facing methods
-    def new_vectors(self, arg=0, dim=None):
+    def new_vectors(self, arg=0, dim=None, data_type=None):
+        # data_type is an extension (mixed-precision work blocks); the reference has (arg, dim)
         if isinstance(arg, numbers.Number):
-            return Vectors(self.dimension() if dim is None else dim, int(arg), self.data_type())
+            return Vectors(self.dimension() if dim is None else dim, int(arg),
+                           self.data_type() if data_type is None else data_type)
         return Vectors(arg)
 
     def dimension(self):
@@ -304,6 +306,13 @@ class Vectors:
         bv = np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=self._dtype), (m,)))
         _lib.check(_lib.lib().rlh_lincomb_cols(self._code, self._vdim, m, _lib.host_ptr(av), x._ptr(), x._ld,
                                                _lib.host_ptr(bv), y._ptr(), y._ld, self._ptr(), self._ld))
+
+    def convert_to(self, other):
+        """other = self converted to other's precision (float32 <-> float64, complex64 <-> complex128)."""
+        if other.nvec() != self.nvec() or other._vdim != self._vdim:
+            raise ValueError('mismatching shapes in convert_to()')
+        _lib.check(_lib.lib().rlh_convert(self._code, other._code, self._vdim, self.nvec(), self._ptr(), self._ld,
+                                          other._ptr(), other._ld))
 
     # ------------------------------------------------------------ other methods of the reference backends
     def shape(self):

@@ -290,6 +290,16 @@ __global__ __launch_bounds__(256) void conj_kernel(R *X, int64_t ldx_r, int64_t 
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) x[2 * r + 1] = -x[2 * r + 1];
 }
 
+// precision conversion of a block (mixed-precision preconditioning): Y = (TD) X
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS *__restrict__ X, int64_t ldx, TD *__restrict__ Y,
+                                                      int64_t ldy, int64_t n) {
+  const TS *x = X + (int64_t)blockIdx.y * ldx;
+  TD *y = Y + (int64_t)blockIdx.y * ldy;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) y[r] = (TD)x[r];
+}
+
 static inline unsigned row_blocks(int64_t items, int64_t m) {
   Context &c = ctx();
   int64_t nb = (items + 256 * 4 - 1) / (256 * 4);            // ~4 items per lane
@@ -540,6 +550,29 @@ int rlh_scale_cols(int dtype, int64_t n, int64_t m, const double *s, int mode, v
   int rc = 0;
   RLH_DISPATCH(dtype, scale_cols_impl, n, m, s, mode, X, ldx)
   return rc;
+}
+
+int rlh_convert(int src_dtype, int dst_dtype, int64_t n, int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(src_dtype) && dtype_valid(dst_dtype), "rlh_convert: unknown dtype");
+  const bool cs = (src_dtype == RLH_C || src_dtype == RLH_Z), cd = (dst_dtype == RLH_C || dst_dtype == RLH_Z);
+  RLH_REQUIRE(cs == cd, "rlh_convert: real <-> complex conversion is not supported");
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_convert: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(X && Y && ldx >= n && ldy >= n, "rlh_convert: bad arguments");
+  if (src_dtype == dst_dtype) return rlh_copy(src_dtype, n, m, X, ldx, Y, ldy);
+  // complex blocks are converted as real blocks of twice the length
+  const int64_t f = cs ? 2 : 1;
+  const bool src_single = (src_dtype == RLH_S || src_dtype == RLH_C);
+  dim3 grid(row_blocks(n * f, m), (unsigned)m);
+  if (src_single)
+    hipLaunchKernelGGL((convert_kernel<float, double>), grid, dim3(256), 0, ctx().stream, (const float *)X, ldx * f,
+                       (double *)Y, ldy * f, n * f);
+  else
+    hipLaunchKernelGGL((convert_kernel<double, float>), grid, dim3(256), 0, ctx().stream, (const double *)X, ldx * f,
+                       (float *)Y, ldy * f, n * f);
+  RLH_HIP(hipGetLastError());
+  return 0;
 }
 
 int rlh_conj(int dtype, int64_t n, int64_t m, void *X, int64_t ldx) {

@@ -243,6 +243,11 @@ class FakeLib:
         x[:, :] = ops.scale_cols(x, sv, bool(mode))
         return 0
 
+    def rlh_convert(self, src, dst, n, m, X, ldx, Y, ldy):
+        self._count('convert')
+        _block(Y, dst, n, m, ldy)[:, :] = _block(X, src, n, m, ldx).astype(_DT[dst])
+        return 0
+
     def rlh_conj(self, code, n, m, X, ldx):
         if code in (2, 3):
             x = _block(X, code, n, m, ldx)

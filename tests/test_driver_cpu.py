@@ -248,3 +248,23 @@ def test_fused_chebyshev_step_equals_unfused():
     assert np.allclose(dn.data(), dn1, rtol=1e-13, atol=1e-12)
     assert np.allclose(y.data(), y0 + dn1, rtol=1e-13, atol=1e-12)
     assert np.array_equal(d.data(), d0)
+
+
+def test_mixed_precision_chebyshev_preconditioner():
+    """The polynomial evaluated in float32 (converted on the device): fp64 eigenvalues are unaffected."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip import SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
+    from oracle.sparse import lap3d, lap3d_eigenvalues
+    A = lap3d(20, 19, 18, 1.0, 1.01, 1.02)
+    ana = lap3d_eigenvalues(20, 19, 18, 1.0, 1.01, 1.02, 6)
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 500
+    T = ChebyshevPreconditioner(None, gershgorin_upper_bound(A), ratio=100, degree=6,
+                                low_precision_op=SparseSymmetricMatrix(A.astype(np.float32)))
+    lmd, x, status = partial_hevp(A, T=T, which=6, tol=1e-7, verb=-1, opt=opt)
+    assert status == 0
+    assert np.max(np.abs(lmd[:6] - ana) / ana) < 1e-10
+    assert partial_hevp.last['iterations'] < 60
