@@ -104,6 +104,14 @@ def main():
     assert status == 0, status
     assert np.max(np.abs(lmd2[:4] - ana) / ana) < 1e-10
     assert fake_lib_calls().get('spmm_cheb', 0) > 10
+    # ... and with the polynomial evaluated in float32 on a float32 copy of the sharded operator
+    np.random.seed(1)
+    op32 = ShardedSparseMatrix(A.astype(np.float32), comm)
+    T = ChebyshevPreconditioner(None, gershgorin_upper_bound(A), ratio=100, degree=6, low_precision_op=op32)
+    lmd3, x3, status = partial_hevp(None, T=T, which=4, tol=1e-8, verb=-1, opt=opt, vectors=mk, operator=op)
+    assert status == 0, status
+    assert np.max(np.abs(lmd3[:4] - ana) / ana) < 1e-10
+    assert fake_lib_calls().get('convert', 0) > 10
 
     # row-sharded dense operator and PCA (BASELINE config 4 layout): same answer as one rank
     from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix

@@ -139,3 +139,27 @@ def test_device_chebyshev_preconditioner_n1e6():
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-2 * 1e-3 * np.max(np.abs(A.diagonal()))
     assert np.allclose(x.T @ x, np.eye(x.shape[1]), atol=1e-7)
     assert partial_hevp.last['iterations'] < 100
+
+
+def test_mixed_precision_chebyshev_preconditioner_n1e6():
+    """The same solve with the polynomial evaluated in float32 on a float32 copy of the operator
+    (rlh_convert in and out): the preconditioner only steers the search directions, so the fp64
+    eigenvalues keep their 1e-10 accuracy and the iteration count does not grow."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip import SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
+    from oracle.sparse import lap3d, lap3d_eigenvalues
+    A = lap3d(100, 100, 100, 1.0, 1.01, 1.02)
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 1000
+    T = ChebyshevPreconditioner(None, gershgorin_upper_bound(A), ratio=1000, degree=12,
+                                low_precision_op=SparseSymmetricMatrix(A.astype(np.float32)))
+    lmd, x, status = partial_hevp(A, T=T, which=10, tol=1e-6, verb=-1, opt=opt)
+    assert status == 0 and len(lmd) >= 10
+    ana = lap3d_eigenvalues(100, 100, 100, 1.0, 1.01, 1.02, 10)
+    assert np.max(np.abs(lmd[:10] - ana) / ana) < 1e-10
+    r = A @ x[:, :10] - x[:, :10] * lmd[:10]
+    assert np.max(np.linalg.norm(r, axis=0)) < 1e-2 * 1e-3 * np.max(np.abs(A.diagonal()))
+    assert partial_hevp.last['iterations'] < 100

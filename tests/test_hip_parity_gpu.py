@@ -301,3 +301,23 @@ def test_fused_chebyshev_step(key):
     assert cases.rel(dn.data(), dn1) < 1e-13
     assert cases.rel(y.data(), y0 + dn1) < 1e-13
     assert np.array_equal(d.data(), d0)
+
+
+@pytest.mark.parametrize('src,dst', [('d', 's'), ('s', 'd'), ('z', 'c'), ('c', 'z'), ('d', 'd')])
+def test_convert_precision(src, dst):
+    """rlh_convert / Vectors.convert_to: element-wise rounding identical to NumPy's astype, on a
+    column window with different leading dimensions on the two sides."""
+    from raleigh_amd.algebra.hip import Vectors
+    rng = np.random.default_rng(17)
+    n, m = 100003, 9
+    x0 = rnd((m, n), src, rng)
+    X = Vectors(x0.copy())
+    Y = Vectors(n, m + 2, data_type=DT[dst])
+    Y.fill(np.repeat(np.arange(1, m + 3)[:, None], n, axis=1).astype(DT[dst]))
+    X.select(5, 2)
+    Y.select(5, 4)
+    X.convert_to(Y)
+    Y.select(m + 2, 0)
+    y = Y.data()
+    assert np.array_equal(y[4:9], x0[2:7].astype(DT[dst]))
+    assert np.all(y[:4] == np.arange(1, 5)[:, None]) and np.all(y[9:] == np.arange(10, m + 3)[:, None])
