@@ -14,9 +14,19 @@
 // The kernel is HBM-bound: nnz*(s+4) matrix bytes + one read of X + one write of Y.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "common.h"
+
+// Per-block record of the windowed layout (see "Windowed ELL" below).
+struct WellMeta {
+  int64_t eoff;            // first entry slot of the block, in units of 1024 entries
+  int32_t goff;            // first staging group of the block in `gsrc`
+  int32_t width_ng;        // entry slots per row (low 8 bits) | staging groups per vector << 8
+};
 
 struct rlh_csr {
   int dtype;
@@ -27,6 +37,19 @@ struct rlh_csr {
   int32_t *cols;           // device, padded
   void *vals;              // device, padded
   int64_t device_bytes;
+  // windowed layout (used instead of the sliced one when the matrix has column locality)
+  int64_t well_blocks;     // 0: not built
+  int well_wmax;           // 8 / 16 / 32: register slots per row the kernel is instantiated for
+  WellMeta *well_meta;     // device, well_blocks
+  int32_t *well_gsrc;      // device: first column of every 64-entry staging group
+  uint16_t *well_idx;      // device: position of the entry's column in the staged image
+  void *well_vals;         // device
+  double well_ratio;       // staged elements per stored entry slot (diagnostic)
+  int32_t *well_sched;     // device: block processed at launch position p (-1: none)
+  int64_t well_sched_len;
+  int well_grid;           // workgroups the schedule was laid out for
+  int well_inbounds;       // every staging group lies inside [0, n_cols)
+  int well_aligned;        // every staging group starts on a multiple of 4 columns
 };
 
 namespace rlh {
@@ -217,6 +240,247 @@ static int launch_spmm(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int
   return launch_spmm_t<T, JT, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 
+
+// ------------------------------------------------------------------ Windowed ELL
+// The sliced kernel above is limited by the rate at which a CU's vector-memory path retires
+// per-lane gathers (one 8-byte gather per stored entry and vector: measured ~19 cycles per
+// 512-byte wave gather whatever the locality, profiles/r01_spmm_sweep2.txt), not by HBM.  For
+// matrices with column locality (banded, stencil, FE after a bandwidth-reducing ordering) the
+// gathers of a block of rows fall into a few contiguous column windows, so this layout moves
+// them to the LDS, whose read rate is 8x higher:
+//  * rows are cut into blocks of 1024 (one row per thread of a 1024-thread workgroup, 16 waves);
+//  * per block the referenced columns are merged into windows (gaps <= 32 columns are bridged),
+//    each padded to a multiple of 64 columns: a "staging group" is 64 consecutive columns that
+//    one wave copies from the block of vectors into the LDS with one coalesced load;
+//  * an entry stores its value and the 16-bit position of its column in the staged image;
+//    the entries of the thread's row stay in registers for all the vectors of the block;
+//  * per step the workgroup computes as many vectors as one LDS buffer holds while the loads that
+//    fill the other buffer with the next ones are in flight (register-staged double buffer,
+//    one barrier per step).
+// Each element of X is then loaded once per window it lies in (3.4x for the 7-point stencil on
+// 215^3: centre + y neighbours in one window, the two z planes in one each) instead of once per
+// entry (7x), and the seven reads per row come out of the LDS.
+template <typename T> struct WellCfg { static constexpr int SMAX = sizeof(T) >= 16 ? 4 : 8; };   // <= 64 KiB per buffer
+constexpr int kWellRows = 1024;
+
+// 16-byte pieces of a block of vectors: natural alignment of T on the global side (a group may
+// start on any column), 16 bytes on the LDS side.
+template <typename T, int EPL> struct VecU { T e[EPL]; };
+template <typename T, int EPL> struct alignas(16) VecA { T e[EPL]; };
+
+template <typename T, int WMAX, int EPL, bool CHEB>
+__global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restrict__ meta,
+                                                         const int32_t *__restrict__ gsrc,
+                                                         const uint16_t *__restrict__ idx,
+                                                         const T *__restrict__ vals, int64_t n_rows, int64_t n_cols,
+                                                         const int32_t *__restrict__ sched, int64_t sched_len,
+                                                         const T *__restrict__ X, int64_t ldx,
+                                                         int64_t n_own, const T *__restrict__ H, int64_t ldh,
+                                                         T *__restrict__ Y, int64_t ldy, int m, int cps_cap,
+                                                         ChebArgs<T> cheb) {
+  constexpr int SMAX = WellCfg<T>::SMAX;      // staging loads per thread and step
+  constexpr int BUF = kWellRows * SMAX;       // elements per LDS buffer
+  __shared__ T lds[2 * BUF];
+  char *ldsb = reinterpret_cast<char *>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const unsigned lane8 = (unsigned)lane * (unsigned)sizeof(T);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T *Hs = H ? H - n_own : X;            // halo row of column c: Hs[c]
+  const int last_col = (int)(n_cols - 1);
+  // The step bodies below are straight-line on purpose: every load and LDS write of a step is
+  // issued unconditionally (surplus staging slots repeat the step's last group, entry slots past
+  // the block's width are zeroed), so the compiler keeps counted vmcnt waits and the loads of two
+  // steps really are in flight together; with per-load predicates it waited for vmcnt(0) before
+  // every load.
+  for (int64_t pos = blockIdx.x; pos < sched_len; pos += gridDim.x) {
+    const int64_t b = sched[pos];
+    if (b < 0) continue;
+    const WellMeta mt = meta[b];
+    const int width = mt.width_ng & 255;
+    const int ng = mt.width_ng >> 8;          // >= 1
+    const int F = ng * 64;                    // staged elements per vector
+    // vectors per step: as many as the LDS buffer holds, evened out over the steps
+    int cps = (16 * SMAX) / ng;
+    if (cps > cps_cap) cps = cps_cap;
+    if (cps > m) cps = m;
+    const int nsteps = (m + cps - 1) / cps;
+    cps = (m + nsteps - 1) / nsteps;
+    const int G = ng * cps;                   // staging groups per step
+    const int64_t row = b * kWellRows + tid;
+    // the row's entries: registers for the whole block of vectors (slots past the block's width
+    // read the next block's entries -- the arrays are padded -- and are zeroed)
+    T v[WMAX];
+    unsigned ixb[WMAX];                       // byte offset of the entry's column in a staged vector
+#pragma unroll
+    for (int t = 0; t < WMAX; ++t) {
+      const int64_t e = (mt.eoff + t) * kWellRows + tid;
+      const T val = nt_load(vals + e);
+      const unsigned pos_t = __builtin_nontemporal_load(idx + e);
+      v[t] = t < width ? val : zero_of(T{});
+      ixb[t] = t < width ? pos_t * (unsigned)sizeof(T) : 0u;
+    }
+    // this thread's share of a step's staging: one load moves EPL elements per lane, i.e. EPL
+    // consecutive 64-column groups per wave; slot i of the wave covers groups q .. q + EPL - 1,
+    // q = EPL (wave + 16 i), of the step's G (vector cc = q / ng of the step, groups q % ng .. of
+    // the block: ng is a multiple of 4, so a slot never straddles two vectors)
+    constexpr int SLOTS = SMAX / EPL;
+    constexpr int LPG = 64 / EPL;             // lanes per group
+    int sbase[SLOTS];                         // byte offset of the slot's groups in an LDS buffer (wave-uniform)
+    int scc[SLOTS];                           // vector within the step (wave-uniform)
+    int scol[SLOTS];                          // first column this lane reads
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      int q = (wave + 16 * i) * EPL;
+      if (q > G - EPL) q = G - EPL;           // surplus slots repeat the last groups
+      const int cc = q / ng, g = q - cc * ng;
+      scc[i] = __builtin_amdgcn_readfirstlane(cc);
+      sbase[i] = __builtin_amdgcn_readfirstlane((cc * F + g * 64) * (int)sizeof(T));
+      if constexpr (EPL == 1)
+        scol[i] = __builtin_amdgcn_readfirstlane(gsrc[mt.goff + g]);
+      else
+        scol[i] = gsrc[mt.goff + g + lane / LPG] + (lane % LPG) * EPL;
+    }
+    VecU<T, EPL> stA[SLOTS], stB[SLOTS];
+    auto stage_load = [&](int s, VecU<T, EPL> (&st)[SLOTS]) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        int j = s * cps + scc[i];
+        if (j > m - 1) j = m - 1;             // a short last step re-reads the last vector
+        int c;
+        if constexpr (EPL == 1) {
+          c = scol[i] + lane;
+          if (c > last_col) c = last_col;     // group padding past the last column re-reads it
+        } else {
+          c = scol[i];                        // the host checked: groups in range, pieces on one side of n_own
+        }
+        const T *src = c < n_own ? X + (int64_t)j * ldx : Hs + (int64_t)j * ldh;
+        st[i] = *reinterpret_cast<const VecU<T, EPL> *>(src + c);
+      }
+    };
+    // LDS addresses are formed at the point of use from an opaque scalar (the byte offset of the
+    // buffer, or of the vector in it) plus a per-thread register: left to itself the compiler
+    // hoists one address register per (buffer, vector, entry) out of the step loop and spills.
+    auto stage_write = [&](int s, const VecU<T, EPL> (&st)[SLOTS]) {
+      unsigned boff = (unsigned)(s & 1) * (unsigned)(BUF * sizeof(T));
+      asm volatile("" : "+s"(boff));
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        VecA<T, EPL> val;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) val.e[k] = st[i].e[k];
+        *reinterpret_cast<VecA<T, EPL> *>(ldsb + (lane8 * EPL + (boff + (unsigned)sbase[i]))) = val;
+      }
+    };
+    auto compute = [&](int s) {
+      unsigned boff = (unsigned)(s & 1) * (unsigned)(BUF * sizeof(T));
+      int j = s * cps;
+      const int jend = (j + cps < m) ? j + cps : m;
+      for (; j < jend; ++j) {
+        asm volatile("" : "+s"(boff));
+        T acc = zero_of(T{});
+#pragma unroll
+        for (int t = 0; t < WMAX; ++t) fma_acc(acc, v[t], *reinterpret_cast<const T *>(ldsb + (ixb[t] + boff)));
+        if (row < n_rows) {
+          if constexpr (!CHEB) {
+            nt_store(Y + row + (int64_t)j * ldy, acc);
+          } else {
+            T *rp = cheb.R + row + (int64_t)j * cheb.ldr;
+            const T rr = sub_of(*rp, acc);                                      // r -= A d
+            const T dn = add_of(scale_of(cheb.alpha, X[row + (int64_t)j * ldx]), scale_of(cheb.beta, rr));
+            *rp = rr;
+            cheb.Dn[row + (int64_t)j * cheb.lddn] = dn;                         // dn = alpha d + beta r
+            T *yp = Y + row + (int64_t)j * ldy;
+            *yp = add_of(*yp, dn);                                              // y += dn
+          }
+        }
+        boff += (unsigned)F * (unsigned)sizeof(T);
+      }
+    };
+    // Two register sets: the loads of step s + 2 are issued at the start of step s and written to
+    // the LDS at the end of step s + 1, so they have two steps (and two barriers, which plain
+    // loads survive) to arrive.
+    stage_load(0, stA);
+    stage_load(nsteps > 1 ? 1 : 0, stB);
+    stage_write(0, stA);
+    __syncthreads();
+    int s = 0;
+    for (; s + 3 < nsteps; s += 2) {          // both prefetch targets exist
+      stage_load(s + 2, stA);                 // B holds step s + 1
+      compute(s);
+      stage_write(s + 1, stB);
+      __syncthreads();
+      stage_load(s + 3, stB);                 // A holds step s + 2
+      compute(s + 1);
+      stage_write(s + 2, stA);
+      __syncthreads();
+    }
+    const int left = nsteps - s;              // 1, 2 or 3 steps, nothing beyond them to prefetch
+    if (left == 3) {
+      stage_load(s + 2, stA);
+      compute(s);
+      stage_write(s + 1, stB);
+      __syncthreads();
+      compute(s + 1);
+      stage_write(s + 2, stA);
+      __syncthreads();
+      compute(s + 2);
+    } else if (left == 2) {
+      compute(s);
+      stage_write(s + 1, stB);
+      __syncthreads();
+      compute(s + 1);
+    } else {
+      compute(s);
+    }
+    __syncthreads();                          // the next block's first stage overwrites the buffers
+  }
+}
+
+template <typename T, int WMAX, int EPL>
+static int launch_well_we(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
+                          T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
+  Context &c = ctx();
+  const int64_t nb = h->well_grid;            // 64-128 KiB of LDS: one workgroup per CU, persistent
+  static const int cps_cap = env_int("RLH_SPMM_CPS", 8);       // vectors per step (tunable)
+  if (cheb)
+    hipLaunchKernelGGL((well_spmm_kernel<T, WMAX, EPL, true>), dim3((unsigned)nb), dim3(1024), 0, c.stream,
+                       h->well_meta, h->well_gsrc, h->well_idx, (const T *)h->well_vals, h->n_rows, h->n_cols,
+                       h->well_sched, h->well_sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                       cps_cap < 1 ? 1 : cps_cap, *cheb);
+  else
+    hipLaunchKernelGGL((well_spmm_kernel<T, WMAX, EPL, false>), dim3((unsigned)nb), dim3(1024), 0, c.stream,
+                       h->well_meta, h->well_gsrc, h->well_idx, (const T *)h->well_vals, h->n_rows, h->n_cols,
+                       h->well_sched, h->well_sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                       cps_cap < 1 ? 1 : cps_cap, ChebArgs<T>{});
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int WMAX>
+static int launch_well_w(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
+                         T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
+  // 16-byte staging loads when every piece is whole: groups inside the column range, and with a
+  // halo block no piece across the own / halo boundary (aligned groups, n_own a multiple of the
+  // piece); the addresses themselves only need T's alignment
+  constexpr int EPL = 16 / (int)sizeof(T);
+  if constexpr (EPL > 1) {
+    static const int vec = env_int("RLH_SPMM_VEC", 1);         // 0: 8-byte staging (tunable)
+    const bool whole = h->well_inbounds && (H == nullptr || n_own == h->n_cols || (h->well_aligned && n_own % EPL == 0));
+    if (vec && whole) return launch_well_we<T, WMAX, EPL>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  }
+  return launch_well_we<T, WMAX, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+}
+
+template <typename T>
+static int launch_well(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
+                       T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
+  if (h->well_wmax <= 8) return launch_well_w<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if constexpr (sizeof(T) == 4)               // 32 register slots of a wider type would spill
+    if (h->well_wmax > 16) return launch_well_w<T, 32>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  return launch_well_w<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+}
+
 template <int DT>
 static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, int64_t n_own, const void *H_,
                      int64_t ldh, void *Y_, int64_t ldy, void *R_ = nullptr, int64_t ldr = 0, void *Dn_ = nullptr,
@@ -227,6 +491,7 @@ static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, i
   T *Y = (T *)Y_;
   ChebArgs<T> cargs{(T *)R_, ldr, (T *)Dn_, lddn, alpha, beta};
   const ChebArgs<T> *cheb = R_ ? &cargs : nullptr;
+  if (h->well_blocks > 0) return launch_well<T>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   static const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
   if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
@@ -305,6 +570,251 @@ static int csr_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, 
   return 0;
 }
 
+
+// Launch order of the windowed layout's blocks.  Workgroup w of the persistent grid processes
+// sched[w], sched[w + grid], ...; workgroups w and w + 8 share an XCD and its L2 under the
+// observed round-robin placement, so the 32 positions {r * grid + 8 i + x, i < 32} are blocks that
+// XCD x works on at the same time.  A block's windows are mostly the own rows of other blocks
+// (the z planes of a 3-D stencil are the rows of the blocks ~n_y n_x / 1024 further on): the
+// schedule makes such blocks concurrent on one XCD, so that the window one of them stages is an
+// L2 hit left by the block that owns those rows, instead of a second and third trip over the fabric
+// (speed only: any order gives the same result).  Greedy: a group of 32 is grown from the lowest
+// unscheduled block by repeatedly adding the unscheduled block that overlaps most with the group.
+template <typename WinVec>
+static void well_schedule(const std::vector<WinVec> &wins, int64_t nblocks, int64_t n_rows, int num_cu,
+                          std::vector<int32_t> &sched, int &grid) {
+  const int xcds = 8;
+  int per_xcd = num_cu / xcds;
+  if (per_xcd < 1) per_xcd = 1;
+  if (nblocks <= xcds * per_xcd || env_int("RLH_SPMM_SCHED", 1) == 0) {
+    grid = (int)std::min<int64_t>(nblocks, (int64_t)xcds * per_xcd);
+    sched.resize((size_t)nblocks);
+    for (int64_t b = 0; b < nblocks; ++b) sched[b] = (int32_t)b;
+    return;
+  }
+  grid = xcds * per_xcd;
+  // overlap graph: weight = rows of block c that block b stages (both directions)
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> adj((size_t)nblocks);
+  for (int64_t b = 0; b < nblocks; ++b)
+    for (const auto &w : wins[b]) {
+      int64_t lo = w.start, hi = (int64_t)w.start + w.len;
+      if (hi > n_rows) hi = n_rows;                 // halo columns are not rows of this shard
+      for (int64_t c = lo / kWellRows; c * kWellRows < hi; ++c) {
+        if (c == b) continue;
+        const int64_t ov = std::min<int64_t>(hi, (c + 1) * kWellRows) - std::max<int64_t>(lo, c * kWellRows);
+        if (ov <= 0) continue;
+        adj[b].push_back({(int32_t)c, (int32_t)ov});
+        adj[c].push_back({(int32_t)b, (int32_t)ov});
+      }
+    }
+  std::vector<char> done((size_t)nblocks, 0);
+  std::vector<int64_t> weight((size_t)nblocks, 0);
+  std::vector<int32_t> order;
+  order.reserve((size_t)nblocks);
+  int64_t seed = 0;
+  while ((int64_t)order.size() < nblocks) {
+    std::vector<int32_t> touched;
+    int members = 0;
+    auto add = [&](int32_t b) {
+      done[b] = 1;
+      order.push_back(b);
+      ++members;
+      for (const auto &e : adj[b])
+        if (!done[e.first]) {
+          if (weight[e.first] == 0) touched.push_back(e.first);
+          weight[e.first] += e.second;
+        }
+    };
+    while (members < per_xcd && (int64_t)order.size() < nblocks) {
+      int32_t best = -1;
+      for (int32_t c : touched)
+        if (!done[c] && (best < 0 || weight[c] > weight[best] || (weight[c] == weight[best] && c < best))) best = c;
+      if (best < 0) {
+        while (seed < nblocks && done[seed]) ++seed;
+        best = (int32_t)seed;
+      }
+      add(best);
+    }
+    for (int32_t c : touched) weight[c] = 0;
+  }
+  // group g = 8 r + x, member i  ->  position r * grid + 8 i + x
+  const int64_t ngroups = (nblocks + per_xcd - 1) / per_xcd;
+  const int64_t rounds = (ngroups + xcds - 1) / xcds;
+  sched.assign((size_t)(rounds * grid), -1);
+  for (int64_t k = 0; k < nblocks; ++k) {
+    const int64_t g = k / per_xcd, i = k % per_xcd;
+    sched[(size_t)((g / xcds) * grid + i * xcds + g % xcds)] = order[(size_t)k];
+  }
+}
+
+// Host side of the windowed layout.  Returns 0 with h->well_blocks == 0 when the matrix does not
+// qualify (a row longer than 32 entries, a block whose windows do not fit the LDS buffer, or too
+// little column locality for the staging to pay: the sliced layout is built instead).
+template <typename F>
+static void parallel_blocks(int64_t nblocks, F fn) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  if (nt > 16) nt = 16;
+  if ((int64_t)nt > nblocks) nt = (unsigned)(nblocks > 0 ? nblocks : 1);
+  std::atomic<int64_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const int64_t b0 = next.fetch_add(64);
+      if (b0 >= nblocks) break;
+      const int64_t b1 = b0 + 64 < nblocks ? b0 + 64 : nblocks;
+      for (int64_t b = b0; b < b1; ++b) fn(b);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+}
+
+template <int DT>
+static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const void *values_, bool force) {
+  using T = typename DType<DT>::T;
+  constexpr int SMAX = WellCfg<T>::SMAX;
+  constexpr int kGap = 32;                       // columns: smaller holes between windows are bridged
+  const T *values = (const T *)values_;
+  const int64_t n = h->n_rows;
+  const int64_t nblocks = (n + kWellRows - 1) / kWellRows;
+  h->well_blocks = 0;
+  if (nblocks == 0 || h->nnz == 0) return 0;
+  struct Win { int32_t start, len, off; };      // off: position of the window in the staged image
+  std::vector<std::vector<Win>> wins((size_t)nblocks);
+  std::vector<int32_t> width((size_t)nblocks, 0), ngroups((size_t)nblocks, 0);
+  parallel_blocks(nblocks, [&](int64_t b) {
+    const int64_t r0 = b * kWellRows, r1 = (r0 + kWellRows < n) ? r0 + kWellRows : n;
+    int64_t w = 0;
+    for (int64_t r = r0; r < r1; ++r) w = std::max<int64_t>(w, indptr[r + 1] - indptr[r]);
+    width[b] = (int32_t)std::min<int64_t>(w, 1 << 20);
+    std::vector<int32_t> cols(indices + indptr[r0], indices + indptr[r1]);
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    std::vector<Win> &ws = wins[b];
+    const int64_t nc = h->n_cols;
+    // 16-byte staging loads: a window starts on a multiple of 4 columns, and every 64-column group
+    // stays inside the column range where the matrix is wide enough (a window at the far end is
+    // moved left instead of being padded past the last column)
+    auto place = [&](int64_t first, int64_t last, int64_t &start, int64_t &padded) {
+      start = first & ~(int64_t)3;
+      padded = (last - start + 1 + 63) / 64 * 64;
+      if (start + padded > nc && nc >= padded) start = nc - padded;
+    };
+    for (size_t i = 0; i < cols.size();) {
+      size_t k = i;
+      while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= kGap) ++k;
+      int64_t first = cols[i], last = cols[k], start, padded;
+      for (;;) {
+        place(first, last, start, padded);
+        if (ws.empty() || start >= (int64_t)ws.back().start + ws.back().len) break;
+        first = ws.back().start;               // moved onto its predecessor: one window for both
+        ws.pop_back();
+      }
+      ws.push_back(Win{(int32_t)start, (int32_t)(last - start + 1), 0});
+      if (ws.size() > 4096) break;               // hopeless: stop counting
+      i = k + 1;
+    }
+    int32_t off = 0;
+    for (Win &w : ws) {
+      w.off = off;
+      off += (w.len + 63) / 64 * 64;
+      if (off > (1 << 24)) break;
+    }
+    if (ws.empty()) {                            // a block of empty rows still stages one group
+      ws.push_back(Win{0, 1, 0});
+      off = 64;
+    }
+    off = (off + 255) / 256 * 256;               // groups per block: a multiple of 4 (one 16-byte load
+                                                 // covers 2 or 4 groups); the extra ones repeat the last
+    ngroups[b] = off / 64;
+  });
+  int32_t wmax = 0, gmax = 0;
+  int64_t staged = 0, slots = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    wmax = std::max(wmax, width[b]);
+    gmax = std::max(gmax, ngroups[b]);
+    staged += (int64_t)ngroups[b] * 64;
+    slots += (int64_t)width[b] * kWellRows;
+  }
+  h->well_ratio = slots > 0 ? (double)staged / (double)slots : 0.0;
+  if (wmax > (sizeof(T) == 4 ? 32 : 16) || gmax > 16 * SMAX) return 0;
+  // measured (profiles/r01_spmm_windowed.txt): at 0.65 staged elements per entry slot (5-point
+  // stencil) the windowed kernel is 1.27x faster than the sliced one, at 1.06 (a diagonal
+  // matrix) 4 % slower
+  if (!force && staged * 10 > slots * 9) return 0;
+  h->well_wmax = wmax <= 8 ? 8 : (wmax <= 16 ? 16 : 32);
+  std::vector<WellMeta> meta((size_t)nblocks);
+  int64_t eoff = 0;
+  int64_t goff = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    meta[b] = WellMeta{eoff, (int32_t)goff, width[b] | (ngroups[b] << 8)};
+    eoff += width[b];
+    goff += ngroups[b];
+  }
+  RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
+  std::vector<int32_t> gsrc((size_t)goff);
+  const int64_t epad = 32;                       // the kernel reads WMAX slots whatever the block's width
+  std::vector<uint16_t> idx((size_t)(eoff + epad) * kWellRows, 0);
+  std::vector<T> vals((size_t)(eoff + epad) * kWellRows);
+  memset(vals.data() + (size_t)eoff * kWellRows, 0, (size_t)epad * kWellRows * sizeof(T));
+  parallel_blocks(nblocks, [&](int64_t b) {
+    const std::vector<Win> &ws = wins[b];
+    int32_t filled = 0, last = 0;
+    for (const Win &w : ws)
+      for (int32_t g = 0; g < (w.len + 63) / 64; ++g, ++filled) gsrc[meta[b].goff + w.off / 64 + g] = last = w.start + 64 * g;
+    for (; filled < ngroups[b]; ++filled) gsrc[meta[b].goff + filled] = last;
+    const int64_t r0 = b * kWellRows;
+    for (int l = 0; l < kWellRows; ++l) {
+      const int64_t r = r0 + l;
+      const int64_t p = r < n ? indptr[r] : 0, len = r < n ? indptr[r + 1] - p : 0;
+      for (int32_t t = 0; t < width[b]; ++t) {
+        const int64_t e = (meta[b].eoff + t) * kWellRows + l;
+        if (t < len) {
+          const int32_t c = indices[p + t];
+          // last window starting at or before c
+          size_t lo = 0, hi = ws.size();
+          while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (ws[mid].start <= c) lo = mid; else hi = mid;
+          }
+          idx[e] = (uint16_t)(ws[lo].off + (c - ws[lo].start));
+          vals[e] = values[p + t];
+        } else {
+          idx[e] = 0;
+          memset(&vals[e], 0, sizeof(T));
+        }
+      }
+    }
+  });
+  // what the 16-byte staging path may assume
+  h->well_inbounds = 1;
+  h->well_aligned = 1;
+  for (int64_t g = 0; g < goff; ++g) {
+    if ((int64_t)gsrc[g] + 64 > h->n_cols) h->well_inbounds = 0;
+    if (gsrc[g] & 3) h->well_aligned = 0;
+  }
+  std::vector<int32_t> sched;
+  well_schedule(wins, nblocks, n, ctx().num_cu, sched, h->well_grid);
+  h->well_sched_len = (int64_t)sched.size();
+  RLH_HIP(hipMalloc((void **)&h->well_sched, sched.size() * sizeof(int32_t)));
+  RLH_HIP(hipMemcpy(h->well_sched, sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  RLH_HIP(hipMalloc((void **)&h->well_meta, (size_t)nblocks * sizeof(WellMeta)));
+  RLH_HIP(hipMemcpy(h->well_meta, meta.data(), (size_t)nblocks * sizeof(WellMeta), hipMemcpyHostToDevice));
+  RLH_HIP(hipMalloc((void **)&h->well_gsrc, (size_t)std::max<int64_t>(goff, 1) * sizeof(int32_t)));
+  RLH_HIP(hipMemcpy(h->well_gsrc, gsrc.data(), (size_t)goff * sizeof(int32_t), hipMemcpyHostToDevice));
+  const size_t ne = (size_t)(eoff + epad) * kWellRows;
+  RLH_HIP(hipMalloc((void **)&h->well_idx, std::max<size_t>(ne, 1) * sizeof(uint16_t)));
+  RLH_HIP(hipMalloc((void **)&h->well_vals, std::max<size_t>(ne, 1) * sizeof(T)));
+  RLH_HIP(hipMemcpy(h->well_idx, idx.data(), ne * sizeof(uint16_t), hipMemcpyHostToDevice));
+  RLH_HIP(hipMemcpy(h->well_vals, vals.data(), ne * sizeof(T), hipMemcpyHostToDevice));
+  h->padded = eoff * kWellRows;
+  h->device_bytes = nblocks * (int64_t)sizeof(WellMeta) + (int64_t)sched.size() * 4 + goff * 4 + (int64_t)ne * (2 + (int64_t)sizeof(T));
+  h->well_blocks = nblocks;
+  return 0;
+}
+
 }  // namespace rlh
 
 using namespace rlh;
@@ -330,12 +840,28 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   rlh_csr *h = new rlh_csr();
   h->dtype = dtype; h->n_rows = n_rows; h->n_cols = n_cols; h->nnz = nnz;
   h->slice_ptr = nullptr; h->cols = nullptr; h->vals = nullptr;
+  h->well_blocks = 0; h->well_meta = nullptr; h->well_gsrc = nullptr; h->well_idx = nullptr; h->well_vals = nullptr;
+  h->well_ratio = 0.0; h->well_sched = nullptr; h->well_sched_len = 0; h->well_grid = 0; h->well_inbounds = 0; h->well_aligned = 0;
+  // layout: the windowed one when the matrix qualifies, else the sliced one
+  // (RLH_SPMM_FORMAT=sell|well overrides the locality test; read per handle so tests can cover both)
+  const char *fmt = getenv("RLH_SPMM_FORMAT");
+  const bool want_sell = fmt && !strcmp(fmt, "sell"), force_well = fmt && !strcmp(fmt, "well");
   int rc = 0;
-  switch (dtype) {
-    case RLH_S: rc = csr_build<RLH_S>(h, indptr, indices, values); break;
-    case RLH_D: rc = csr_build<RLH_D>(h, indptr, indices, values); break;
-    case RLH_C: rc = csr_build<RLH_C>(h, indptr, indices, values); break;
-    case RLH_Z: rc = csr_build<RLH_Z>(h, indptr, indices, values); break;
+  if (!want_sell) {
+    switch (dtype) {
+      case RLH_S: rc = well_build<RLH_S>(h, indptr, indices, values, force_well); break;
+      case RLH_D: rc = well_build<RLH_D>(h, indptr, indices, values, force_well); break;
+      case RLH_C: rc = well_build<RLH_C>(h, indptr, indices, values, force_well); break;
+      case RLH_Z: rc = well_build<RLH_Z>(h, indptr, indices, values, force_well); break;
+    }
+  }
+  if (rc == 0 && h->well_blocks == 0) {
+    switch (dtype) {
+      case RLH_S: rc = csr_build<RLH_S>(h, indptr, indices, values); break;
+      case RLH_D: rc = csr_build<RLH_D>(h, indptr, indices, values); break;
+      case RLH_C: rc = csr_build<RLH_C>(h, indptr, indices, values); break;
+      case RLH_Z: rc = csr_build<RLH_Z>(h, indptr, indices, values); break;
+    }
   }
   if (rc) { rlh_csr_destroy(h); return rc; }
   *out = h;
@@ -349,6 +875,11 @@ int rlh_csr_destroy(rlh_csr_t h) {
     if (h->slice_ptr) (void)hipFree(h->slice_ptr);
     if (h->cols) (void)hipFree(h->cols);
     if (h->vals) (void)hipFree(h->vals);
+    if (h->well_meta) (void)hipFree(h->well_meta);
+    if (h->well_gsrc) (void)hipFree(h->well_gsrc);
+    if (h->well_idx) (void)hipFree(h->well_idx);
+    if (h->well_vals) (void)hipFree(h->well_vals);
+    if (h->well_sched) (void)hipFree(h->well_sched);
   }
   delete h;
   return 0;
@@ -360,6 +891,14 @@ int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, in
   if (n_cols) *n_cols = h->n_cols;
   if (nnz) *nnz = h->nnz;
   if (device_bytes) *device_bytes = h->device_bytes;
+  return 0;
+}
+
+int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per_slot) {
+  RLH_REQUIRE(h != nullptr, "rlh_csr_layout: null handle");
+  if (layout) *layout = h->well_blocks > 0 ? 1 : 0;
+  if (stored) *stored = h->padded;
+  if (staged_per_slot) *staged_per_slot = h->well_ratio;
   return 0;
 }
 

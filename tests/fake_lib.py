@@ -284,6 +284,9 @@ class FakeLib:
     def rlh_csr_info(self, h, a, b, c, d):
         return 0
 
+    def rlh_csr_layout(self, h, layout, stored, ratio):
+        return 0
+
     def rlh_spmm(self, h, m, X, ldx, n_own, H, ldh, Y, ldy):
         self._count('spmm')
         c = self._csr[_addr(h)]

@@ -321,3 +321,182 @@ def test_convert_precision(src, dst):
     y = Y.data()
     assert np.array_equal(y[4:9], x0[2:7].astype(DT[dst]))
     assert np.all(y[:4] == np.arange(1, 5)[:, None]) and np.all(y[9:] == np.arange(10, m + 3)[:, None])
+
+
+# ---------------------------------------------------------------- both device layouts of the sparse operator
+@pytest.fixture(params=['sell', 'well'])
+def spmm_format(request, monkeypatch):
+    """RLH_SPMM_FORMAT is read by rlh_csr_create per handle: 'sell' = sliced ELL (per-entry
+    gathers), 'well' = windowed ELL (column windows staged through the LDS) even where the
+    locality test would not choose it; a matrix the windowed layout cannot hold falls back."""
+    monkeypatch.setenv('RLH_SPMM_FORMAT', request.param)
+    return request.param
+
+
+def _sym(A, key):
+    """A symmetric real matrix made Hermitian with a skew imaginary part for the complex types."""
+    A = sp.csr_matrix(A)
+    if key in 'cz':
+        S = sp.triu(A, k=1)
+        A = A + 0.5j * S - 0.5j * S.T
+    return sp.csr_matrix(A.astype(DT[key]))
+
+
+@pytest.mark.parametrize('key', KEYS)
+@pytest.mark.parametrize('m', [1, 3, 8, 21, 37])
+def test_spmm_layouts_stencil(spmm_format, key, m):
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    A = _sym(lap3d(23, 19, 17, 1.0, 1.01, 1.02), key)
+    n = A.shape[0]
+    rng = np.random.default_rng(100 + m)
+    x = rnd((m, n), key, rng)
+    op = SparseSymmetricMatrix(A)
+    X, Y = Vectors(x), Vectors(n, m, data_type=DT[key])
+    op.apply(X, Y)
+    assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < (2e-6 if key in 'sc' else 1e-13)
+
+
+@pytest.mark.parametrize('key', ['s', 'd', 'z'])
+def test_spmm_layouts_irregular(spmm_format, key):
+    """Ragged rows up to 30 entries, empty rows, far-away couplings (several windows per block),
+    a last block of 3 rows."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    rng = np.random.default_rng(5)
+    n = 5 * 1024 + 3
+    band = sp.random(n, n, density=0.0, format='lil')
+    rows = rng.integers(0, n, 9000)
+    cols = np.clip(rows + rng.integers(-40, 41, 9000), 0, n - 1)
+    far = rng.integers(0, n, 1500)
+    B = sp.coo_matrix((rng.standard_normal(9000), (rows, cols)), shape=(n, n)).tocsr()
+    Fm = sp.coo_matrix((rng.standard_normal(1500), (far, (far + 2500) % n)), shape=(n, n)).tocsr()
+    A = sp.lil_matrix(B + B.T + Fm + Fm.T + sp.eye(n))
+    A[200:300, :] = 0
+    A[:, 200:300] = 0
+    A[7, 7:33] = 1.5
+    A[7:33, 7] = 1.5
+    A = _sym(sp.csr_matrix(A), key)
+    A.eliminate_zeros()
+    assert np.diff(A.indptr).max() <= 32 and np.diff(A.indptr).min() == 0
+    x = rnd((11, n), key, rng)
+    op = SparseSymmetricMatrix(A)
+    X, Y = Vectors(x), Vectors(n, 11, data_type=DT[key])
+    op.apply(X, Y)
+    assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < (2e-6 if key == 's' else 1e-13)
+
+
+@pytest.mark.parametrize('key', ['s', 'd'])
+def test_spmm_layouts_no_locality(spmm_format, key):
+    """Uniformly random pattern: the windowed layout degenerates to one wide window (forced) or
+    is not chosen; both give the oracle's product."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    rng = np.random.default_rng(8)
+    n = 4000
+    R = sp.random(n, n, density=0.001, random_state=4, format='csr')
+    A = _sym(R + R.T + sp.eye(n), key)
+    x = rnd((6, n), key, rng)
+    op = SparseSymmetricMatrix(A)
+    X, Y = Vectors(x), Vectors(n, 6, data_type=DT[key])
+    op.apply(X, Y)
+    assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < (2e-6 if key == 's' else 1e-13)
+
+
+@pytest.mark.parametrize('key', ['d', 'c'])
+def test_spmm_layouts_halo_block(spmm_format, key):
+    """Row shard of an operator: columns [0, n_own) come from X, the rest from the halo block H
+    (rlh_spmm's n_own / H arguments), windows straddling the two included; plain and fused
+    Chebyshev forms."""
+    import ctypes
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    A = _sym(lap3d(16, 15, 14, 1.0, 1.01, 1.02), key)
+    n = A.shape[0]
+    r0, r1 = 1100, 2300                       # the shard's rows
+    loc = A[r0:r1]
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    # local numbering: own columns first (in order), then the halo columns in ascending global order
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(r1 - r0)
+    newcol[halo] = (r1 - r0) + np.arange(len(halo))
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr),
+                      shape=(r1 - r0, r1 - r0 + len(halo)))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=r1 - r0)
+    rng = np.random.default_rng(2)
+    m = 13
+    x = rnd((m, n), key, rng)
+    X, Hb = Vectors(np.ascontiguousarray(x[:, r0:r1])), Vectors(np.ascontiguousarray(x[:, halo]))
+    Y = Vectors(r1 - r0, m, data_type=DT[key])
+    assert op.layout()[0] == spmm_format
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hb.data_ptr(), Hb.ld())
+    ref = (A @ x.T).T[:, r0:r1]
+    tol = 2e-6 if key == 'c' else 1e-13
+    assert cases.rel(Y.data(), ref) < tol
+    r_0, y_0 = rnd((m, r1 - r0), key, rng), rnd((m, r1 - r0), key, rng)
+    R, Yc, Dn = Vectors(r_0.copy()), Vectors(y_0.copy()), Vectors(r1 - r0, m, data_type=DT[key])
+    op.cheb_step_ptr(m, X, R, Dn, Yc, 0.7, -0.2, Hb.data_ptr(), Hb.ld())
+    rr = r_0 - ref
+    dn = 0.7 * x[:, r0:r1] - 0.2 * rr
+    assert cases.rel(R.data(), rr) < tol and cases.rel(Dn.data(), dn) < tol
+    assert cases.rel(Yc.data(), y_0 + dn) < tol
+
+
+@pytest.mark.parametrize('key', ['s', 'd'])
+def test_fused_chebyshev_step_layouts(spmm_format, key):
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    A = _sym(lap3d(23, 19, 17, 1.0, 1.01, 1.02), key)
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    m = 10
+    d0, r0, y0 = (rnd((m, n), key, rng) for _ in range(3))
+    op = SparseSymmetricMatrix(A)
+    d, r, y, dn = Vectors(d0.copy()), Vectors(r0.copy()), Vectors(y0.copy()), Vectors(n, m, data_type=DT[key])
+    op.cheb_step(d, r, dn, y, 0.3, -1.7)
+    t = ops.csr_sym_apply(sp.triu(A, format='csr'), d0)
+    r1 = r0 - t
+    dn1 = 0.3 * d0 - 1.7 * r1
+    tol = 3e-6 if key == 's' else 1e-13
+    assert cases.rel(r.data(), r1) < tol and cases.rel(dn.data(), dn1) < tol
+    assert cases.rel(y.data(), y0 + dn1) < tol
+    assert np.array_equal(d.data(), d0)
+
+
+def test_layout_choice(monkeypatch):
+    """The locality test: the stencil gets the windowed layout, a random pattern and a matrix
+    with a long row the sliced one; the environment override wins where the layout can hold
+    the matrix."""
+    from raleigh_amd.algebra.hip import CsrOperator
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    A = lap3d(23, 19, 17, 1.0, 1.01, 1.02)
+    lay, stored, ratio = CsrOperator(A).layout()
+    assert lay == 'well' and 7 * 1024 * 7 < stored <= 8 * 1024 * 7 and 0 < ratio < 0.9
+    rng = np.random.default_rng(4)
+    nr = 200000                                   # random couplings: ~12 per row, no column locality
+    i, j = rng.integers(0, nr, 6 * nr), rng.integers(0, nr, 6 * nr)
+    R = sp.coo_matrix((rng.standard_normal(6 * nr), (i, j)), shape=(nr, nr)).tocsr()
+    lay, stored, ratio = CsrOperator(R + R.T + sp.eye(nr)).layout()
+    assert lay == 'sell' and ratio > 0.9
+    D = sp.lil_matrix(A)
+    D[5, :40] = 1.0
+    assert CsrOperator(sp.csr_matrix(D)).layout()[0] == 'sell'
+    monkeypatch.setenv('RLH_SPMM_FORMAT', 'sell')
+    assert CsrOperator(A).layout()[0] == 'sell'
+    monkeypatch.setenv('RLH_SPMM_FORMAT', 'well')
+    assert CsrOperator(sp.csr_matrix(D)).layout()[0] == 'sell'        # a 40-entry row does not fit
+    assert CsrOperator(A.astype(np.float32)).layout()[0] == 'well'
+
+
+def test_spmm_windowed_schedule_many_blocks(monkeypatch):
+    """More blocks than workgroups (335 blocks of 1024 rows): the XCD-aware launch order is a
+    permutation of the blocks, so every row is computed exactly once."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    A = lap3d(70, 70, 70, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((5, n))
+    op = SparseSymmetricMatrix(A)
+    X, Y = Vectors(x), Vectors(n, 5)
+    Y.fill(np.full((5, n), np.nan))
+    op.apply(X, Y)
+    assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < 1e-13

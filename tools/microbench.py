@@ -80,19 +80,19 @@ def main():
             continue
         med, mn = timed(fn)
         print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % (name, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
-    if args.band >= 0 and args.dtype in 'd':
+    if args.band >= 0:
         import scipy.sparse as sp
         offs = list(range(-args.band, args.band + 1))
-        A = sp.diags([np.full(n - abs(o), 1.0 + 0.1 * o) for o in offs], offs, shape=(n, n), format='csr')
+        A = sp.diags([np.full(n - abs(o), 1.0 + 0.1 * o) for o in offs], offs, shape=(n, n), format='csr').astype(dt)
         op = SparseSymmetricMatrix(A)
         nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
         med, mn = timed(lambda: op.apply(X, W))
         print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % ('spmm band %d' % args.band, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
-    if (args.lap or args.lap2d) and args.dtype in 'd':
+    if args.lap or args.lap2d:
         from oracle.sparse import lap3d
         t0 = time.time()
         A = lap3d(args.lap, args.lap, args.lap, 1.0, 1.01, 1.02) if args.lap else lap3d(args.lap2d, args.lap2d, 1, 1.0, 1.01, 1.02)
-        op = SparseSymmetricMatrix(A)
+        op = SparseSymmetricMatrix(A.astype(dt))
         print('lap3d setup %.1f s, nnz=%d' % (time.time() - t0, A.nnz))
         nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
         med, mn = timed(lambda: op.apply(X, W))
