@@ -140,6 +140,12 @@ int rlh_scale_cols(int dtype, int64_t n, int64_t m, const double *s, int mode,
  * preconditioning; not in the reference) */
 int rlh_convert(int src_dtype, int dst_dtype, int64_t n, int64_t m, const void *X,
                 int64_t ldx, void *Y, int64_t ldy);
+/* Vectors.fill_random for large blocks (dense_cublas.py:119-131 draws numpy.random.rand on the
+ * host and uploads: 0.6 s for 10^7 x 20): X[i, j] = uniform in [-1, 1), a pure function of
+ * (seed, col0 + j, row0 + i) -- splitmix64 of the counter, restated in oracle/ops.py
+ * uniform_block -- so row shards generate their rows of one global block; imaginary parts 0. */
+int rlh_fill_random(int dtype, int64_t n, int64_t m, void *X, int64_t ldx, uint64_t seed,
+                    int64_t row0, int64_t col0);
 /* in-place complex conjugate (dense_cublas.py:503-511); no-op for real */
 int rlh_conj(int dtype, int64_t n, int64_t m, void *X, int64_t ldx);
 

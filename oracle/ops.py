@@ -142,3 +142,26 @@ def csr_sym_apply(upper_csr, x):
     d = sp.diags(u.diagonal())
     full = u + u.conj().T - d
     return np.ascontiguousarray((full @ x.T).T).astype(x.dtype, copy=False)
+
+
+def uniform_block(seed, n, m, dtype, row0=0, col0=0):
+    """The counter-based generator behind rlh_fill_random (not in the reference, which draws
+    numpy.random.rand on the host: dense_cublas.py:119-131): element (i, j) of the (m, n) block
+    is 2 u - 1, u = the top 53 (float64) or 24 (float32) bits of splitmix64(seed + (col0 + j) * K1
+    + (row0 + i + 1) * K2) scaled to [0, 1); bit-exact restatement in uint64 arithmetic."""
+    dtype = np.dtype(dtype)
+    real = np.dtype({np.complex64: np.float32, np.complex128: np.float64}.get(dtype.type, dtype.type))
+    with np.errstate(over='ignore'):
+        col = np.uint64(seed) + (np.uint64(col0) + np.arange(m, dtype=np.uint64)) * np.uint64(0x632BE59BD9B4E019)
+        row = (np.uint64(row0) + np.arange(n, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = col[:, None] + row[None, :]
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    if real == np.float64:
+        u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        out = 2.0 * u - 1.0
+    else:
+        u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        out = np.float32(2) * u - np.float32(1)
+    return out.astype(dtype)

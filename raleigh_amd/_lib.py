@@ -54,6 +54,7 @@ SIGNATURES = {
     'rlh_copy_cols': [_int, _i64, _i64, _p, _p, _i64, _p, _i64],
     'rlh_scale_cols': [_int, _i64, _i64, _p, _int, _p, _i64],
     'rlh_convert': [_int, _int, _i64, _i64, _p, _i64, _p, _i64],
+    'rlh_fill_random': [_int, _i64, _i64, _p, _i64, ctypes.c_uint64, _i64, _i64],
     'rlh_conj': [_int, _i64, _i64, _p, _i64],
     'rlh_gather_rows': [_int, _i64, _p, _i64, _p, _i64, _p, _i64],
     'rlh_csr_create': [ctypes.POINTER(_p), _int, _i64, _i64, _p, _p, _p],

@@ -159,6 +159,12 @@ class ShardedVectors(Vectors):
         # the start vectors do not depend on the number of GPUs
         f, m = self.selected()
         r0, r1 = self._offsets[self._comm.rank], self._offsets[self._comm.rank + 1]
+        if m * self._gdim >= self.DEVICE_RANDOM_THRESHOLD:
+            # counter-based device generator: a function of (seed, vector, GLOBAL row), the seed
+            # drawn from the numpy stream that every rank seeds alike
+            if m > 0:
+                self._fill_random_device(r0)
+            return
         for i in range(m):
             row = np.random.rand(1, self._gdim)[:, r0:r1].astype(self.data_type())
             row *= 2

@@ -177,16 +177,29 @@ class Vectors:
     def data_type(self):
         return self._dtype
 
+    # blocks of at least this many elements are filled by the device generator
+    DEVICE_RANDOM_THRESHOLD = 1 << 22
+
     def fill_random(self):
-        # host RNG then H2D, as the reference does (dense_cublas.py:119-131), so that
-        # numpy.random.seed(...) gives the same start vectors on every backend
+        # Small blocks: host RNG then H2D, as the reference does (dense_cublas.py:119-131), so
+        # that numpy.random.seed(...) gives the same start vectors on every backend.  Large
+        # blocks (where the host draw alone costs 0.6 s at 10^7 x 20): the library's counter-based
+        # generator, seeded from the same numpy stream (still reproducible under numpy.random.seed).
         m, n = self.nvec(), self._vdim
         if m < 1:
+            return
+        if m * n >= self.DEVICE_RANDOM_THRESHOLD:
+            self._fill_random_device(0)
             return
         data = np.random.rand(m, n).astype(self.data_type())
         data *= 2
         data -= 1
         upload(self._ptr(), self._ld * self._es, data)
+
+    def _fill_random_device(self, row0):
+        seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+        _lib.check(_lib.lib().rlh_fill_random(self._code, self._vdim, self.nvec(), self._ptr(), self._ld,
+                                              seed, int(row0), 0))
 
     def copy(self, other, ind=None):
         L = _lib.lib()

@@ -300,6 +300,32 @@ __global__ __launch_bounds__(256) void convert_kernel(const TS *__restrict__ X, 
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) y[r] = (TD)x[r];
 }
 
+// Counter-based uniform numbers in [-1, 1) (device side of Vectors.fill_random for large blocks):
+// element (row, col) is a pure function of (seed, col, row) -- splitmix64 of the combined counter --
+// so a row shard generates exactly its rows of the global block whatever the number of ranks.
+// Real part only for the complex types, as the reference's numpy.random.rand fill.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <typename R, int COMPONENTS>
+__global__ __launch_bounds__(256) void fill_random_kernel(R *X, int64_t ldx_r, int64_t n, uint64_t seed, int64_t row0,
+                                                          int64_t col0) {
+  R *x = X + (int64_t)blockIdx.y * ldx_r;
+  const uint64_t colkey = seed + (uint64_t)(col0 + blockIdx.y) * 0x632BE59BD9B4E019ull;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
+    const uint64_t z = splitmix64(colkey + ((uint64_t)(row0 + r) + 1) * 0x9E3779B97F4A7C15ull);
+    R u;
+    if constexpr (sizeof(R) == 8) u = (R)(z >> 11) * (R)(1.0 / 9007199254740992.0);   // 53 bits
+    else u = (R)(z >> 40) * (R)(1.0 / 16777216.0);                                     // 24 bits
+    x[COMPONENTS * r] = (R)2 * u - (R)1;
+    if constexpr (COMPONENTS == 2) x[2 * r + 1] = (R)0;
+  }
+}
+
 static inline unsigned row_blocks(int64_t items, int64_t m) {
   Context &c = ctx();
   int64_t nb = (items + 256 * 4 - 1) / (256 * 4);            // ~4 items per lane
@@ -571,6 +597,24 @@ int rlh_convert(int src_dtype, int dst_dtype, int64_t n, int64_t m, const void *
   else
     hipLaunchKernelGGL((convert_kernel<double, float>), grid, dim3(256), 0, ctx().stream, (const double *)X, ldx * f,
                        (float *)Y, ldy * f, n * f);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+int rlh_fill_random(int dtype, int64_t n, int64_t m, void *X, int64_t ldx, uint64_t seed, int64_t row0, int64_t col0) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_fill_random: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0 && row0 >= 0 && col0 >= 0, "rlh_fill_random: negative size or offset");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(X && ldx >= n, "rlh_fill_random: bad arguments");
+  dim3 grid(row_blocks(n, m), (unsigned)m);
+  hipStream_t st = ctx().stream;
+  switch (dtype) {
+    case RLH_S: hipLaunchKernelGGL((fill_random_kernel<float, 1>), grid, dim3(256), 0, st, (float *)X, ldx, n, seed, row0, col0); break;
+    case RLH_D: hipLaunchKernelGGL((fill_random_kernel<double, 1>), grid, dim3(256), 0, st, (double *)X, ldx, n, seed, row0, col0); break;
+    case RLH_C: hipLaunchKernelGGL((fill_random_kernel<float, 2>), grid, dim3(256), 0, st, (float *)X, 2 * ldx, n, seed, row0, col0); break;
+    case RLH_Z: hipLaunchKernelGGL((fill_random_kernel<double, 2>), grid, dim3(256), 0, st, (double *)X, 2 * ldx, n, seed, row0, col0); break;
+  }
   RLH_HIP(hipGetLastError());
   return 0;
 }

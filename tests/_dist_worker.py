@@ -58,6 +58,15 @@ def main():
         np.random.seed(11)
         expect = (2 * np.random.rand(3, n) - 1).astype(dt)
         assert np.linalg.norm(R.data() - expect) < 1e-6 * np.linalg.norm(expect)
+        # ... nor does the large-block form (library generator keyed by the GLOBAL row)
+        old_thr = ShardedVectors.DEVICE_RANDOM_THRESHOLD
+        ShardedVectors.DEVICE_RANDOM_THRESHOLD = 1000
+        np.random.seed(11)
+        R.fill_random()
+        ShardedVectors.DEVICE_RANDOM_THRESHOLD = old_thr
+        np.random.seed(11)
+        seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+        assert np.array_equal(R.data(), ops.uniform_block(seed, n, 3, dt))
         c = X.clone()
         assert isinstance(c, ShardedVectors) and np.array_equal(c.data(), x)
 

@@ -248,6 +248,12 @@ class FakeLib:
         _block(Y, dst, n, m, ldy)[:, :] = _block(X, src, n, m, ldx).astype(_DT[dst])
         return 0
 
+    def rlh_fill_random(self, code, n, m, X, ldx, seed, row0, col0):
+        self._count('fill_random')
+        if n and m:
+            _block(X, code, n, m, ldx)[:, :] = ops.uniform_block(int(seed), n, m, _DT[code], row0, col0)
+        return 0
+
     def rlh_conj(self, code, n, m, X, ldx):
         if code in (2, 3):
             x = _block(X, code, n, m, ldx)

@@ -500,3 +500,33 @@ def test_spmm_windowed_schedule_many_blocks(monkeypatch):
     Y.fill(np.full((5, n), np.nan))
     op.apply(X, Y)
     assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < 1e-13
+
+
+@pytest.mark.parametrize('key', KEYS)
+def test_fill_random_bit_exact(key):
+    """rlh_fill_random against its oracle restatement: bit-exact, with row / vector offsets and
+    a leading dimension larger than the block."""
+    import ctypes
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors
+    n, m = 70001, 5
+    V = Vectors(n, m + 1, data_type=DT[key])
+    V.fill(np.full((m + 1, n), 7, dtype=DT[key]))
+    V.select(m, 1)
+    _lib.check(_lib.lib().rlh_fill_random(_lib.DTYPE_CODE[DT[key]], n, m, V.data_ptr(), V.ld(),
+                                          0x123456789ABCDEF, 1000, 2))
+    V.select(m + 1, 0)
+    got = V.data()
+    assert np.array_equal(got[1:], ops.uniform_block(0x123456789ABCDEF, n, m, DT[key], row0=1000, col0=2))
+    assert np.all(got[0] == 7)
+
+
+def test_fill_random_large_block_uses_device_generator():
+    from raleigh_amd.algebra.hip import Vectors
+    n, m = 1 << 20, 5                                   # 5 M elements >= DEVICE_RANDOM_THRESHOLD
+    V = Vectors(n, m)
+    np.random.seed(3)
+    V.fill_random()
+    np.random.seed(3)
+    seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+    assert np.array_equal(V.data(), ops.uniform_block(seed, n, m, np.float64))

@@ -60,3 +60,31 @@ def test_missing_library_fails_loudly(monkeypatch):
     from raleigh_amd.algebra.hip import Vectors
     with pytest.raises(_lib.RlhError):
         Vectors(10, 2)
+
+
+def test_fill_random_device_path(fake, monkeypatch):
+    """Large blocks take the library generator (rlh_fill_random) seeded from the numpy stream:
+    reproducible under numpy.random.seed, uniform in [-1, 1), small blocks keep the reference's
+    host draw (same numbers as numpy.random.rand)."""
+    from raleigh_amd.algebra.hip import Vectors
+    from oracle import ops
+    v = Vectors(1000, 3)
+    np.random.seed(7)
+    v.fill_random()
+    np.random.seed(7)
+    assert np.array_equal(v.data(), 2 * np.random.rand(3, 1000) - 1)       # host path, as the reference
+    assert fake.calls.get('fill_random', 0) == 0
+    monkeypatch.setattr(Vectors, 'DEVICE_RANDOM_THRESHOLD', 2000)
+    np.random.seed(7)
+    v.fill_random()
+    first = v.data()
+    assert fake.calls.get('fill_random', 0) == 1
+    np.random.seed(7)
+    seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+    assert np.array_equal(first, ops.uniform_block(seed, 1000, 3, np.float64))
+    v.fill_random()                                    # the next draw of the stream: another block
+    assert not np.array_equal(v.data(), first)
+    assert first.min() >= -1 and first.max() < 1 and abs(first.mean()) < 0.05
+    c = Vectors(1000, 3, data_type=np.complex64)
+    c.fill_random()
+    assert np.all(c.data().imag == 0) and c.data().real.std() > 0.5

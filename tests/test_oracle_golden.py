@@ -150,3 +150,21 @@ def test_lap3d_analytic_vs_reference_solver(golden_dir):
     ref10 = np.array(k['hevp_lap30_ilu10']['eigenvalues'])
     ana10 = lap3d_eigenvalues(30, 30, 30, 1.0, 1.01, 1.02, 10)
     assert np.max(np.abs(ref10 - ana10) / ana10) < 1e-8
+
+
+def test_uniform_block_generator():
+    """The counter-based generator behind rlh_fill_random: vector 0 of seed s is the splitmix64
+    stream of s (published test vector for s = 1234567), rows / vectors can be generated in
+    shards, values are uniform in [-1, 1)."""
+    from oracle import ops
+    z = [6457827717110365317, 3203168211198807973, 9817491932198370423]
+    want = np.array([(v >> 11) * 2.0 ** -53 * 2 - 1 for v in z])
+    assert np.array_equal(ops.uniform_block(1234567, 3, 1, np.float64)[0], want)
+    full = ops.uniform_block(99, 700, 5, np.float64)
+    assert np.array_equal(ops.uniform_block(99, 300, 5, np.float64, row0=250), full[:, 250:550])
+    assert np.array_equal(ops.uniform_block(99, 700, 2, np.float64, col0=3), full[3:])
+    assert full.min() >= -1 and full.max() < 1 and abs(full.mean()) < 0.03 and abs(full.std() - 3 ** -0.5) < 0.02
+    f32 = ops.uniform_block(99, 700, 5, np.float32)
+    assert f32.dtype == np.float32 and np.max(np.abs(f32 - full)) < 2e-7
+    c = ops.uniform_block(99, 700, 5, np.complex128)
+    assert np.array_equal(c.real, full) and np.all(c.imag == 0)
