@@ -266,14 +266,19 @@ class ShardedSparseMatrix:
         own = (cols >= r0) & (cols < r1)
         halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
         owner = np.searchsorted(off, halo_cols, side='right') - 1
+        # local column numbering: own rows first, then the halo rows from a multiple of 4 on (the
+        # 1-3 columns in between are never referenced: they are the padding of the local block's
+        # leading dimension), so that no 16-byte piece of the library's staging loads lies across
+        # the own / halo boundary whatever the shard size
+        n_own_pad = -(-(r1 - r0) // 4) * 4
         new_idx = np.empty_like(cols)
         new_idx[own] = cols[own] - r0
-        new_idx[~own] = (r1 - r0) + np.searchsorted(halo_cols, cols[~own])
+        new_idx[~own] = n_own_pad + np.searchsorted(halo_cols, cols[~own])
         ext = scs.csr_matrix((loc.data, new_idx.astype(np.int32), loc.indptr),
-                             shape=(r1 - r0, (r1 - r0) + halo_cols.size))
+                             shape=(r1 - r0, n_own_pad + halo_cols.size))
         self._n_own = r1 - r0
         self._n_halo = int(halo_cols.size)
-        self._op = CsrOperator(ext, n_own=self._n_own)
+        self._op = CsrOperator(ext, n_own=n_own_pad)
         self._nnz = nnz_global
         # receive plan: contiguous runs of halo rows per owner
         self._recv = []                                       # (peer, halo_start, count)

@@ -400,8 +400,9 @@ def test_spmm_layouts_no_locality(spmm_format, key):
     assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < (2e-6 if key == 's' else 1e-13)
 
 
+@pytest.mark.parametrize('rows', [(1100, 2300), (1101, 2302)])
 @pytest.mark.parametrize('key', ['d', 'c'])
-def test_spmm_layouts_halo_block(spmm_format, key):
+def test_spmm_layouts_halo_block(spmm_format, key, rows):
     """Row shard of an operator: columns [0, n_own) come from X, the rest from the halo block H
     (rlh_spmm's n_own / H arguments), windows straddling the two included; plain and fused
     Chebyshev forms."""
@@ -410,7 +411,8 @@ def test_spmm_layouts_halo_block(spmm_format, key):
     from raleigh_amd.algebra.hip import Vectors, CsrOperator
     A = _sym(lap3d(16, 15, 14, 1.0, 1.01, 1.02), key)
     n = A.shape[0]
-    r0, r1 = 1100, 2300                       # the shard's rows
+    r0, r1 = rows                             # the shard's rows (1201 of them: the own / halo boundary
+                                              # is then not a multiple of the 16-byte staging piece)
     loc = A[r0:r1]
     used = np.unique(loc.indices)
     halo = used[(used < r0) | (used >= r1)]
