@@ -52,8 +52,14 @@ struct GramArgs {
 
 // (three resident workgroups per CU measured faster in sustained back-to-back use than the four that
 // __launch_bounds__(256, 4) gives: 5.97 vs 5.53 TB/s)
-template <int DT, int PI, int PJ, bool ALIGNED>
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+// MODE 0: general (unaligned layouts, several panels of a self-Gram): loads predicated per piece,
+//         one chunk in flight.
+// MODE 1 / 2: aligned two-operand Gram / aligned single-panel self-Gram: the panel shape is known
+//         at compile time, so the loads of a chunk are straight-line code and the loop keeps TWO
+//         chunks in flight in two register sets (the compiler emits counted vmcnt waits only for
+//         straight-line load groups: with a predicate per load it waits for vmcnt(0)).
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE>
+__global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) void gram_kernel(GramArgs a) {
   using T = typename DType<DT>::T;
   using R = typename DType<DT>::R;
   using M = Mfma16<R>;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int panel = blockIdx.y;
   const int pi = panel / a.npj, pj = panel % a.npj;
-  const bool same_panel = a.same && (pi == pj) && (PI == PJ);
+  const bool same_panel = MODE == 2 ? true : (MODE == 1 ? false : (a.same && (pi == pj) && (PI == PJ)));
   const int cy0 = pi * CY, cx0 = pj * CX;        // first T column of the panels
   const int units_y = same_panel ? 0 : CY * UPC;
   const int nunits = units_y + CX * UPC;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     }
   };
 
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](const vec_t (&regs)[UPT]) {
 #pragma unroll
     for (int q = 0; q < UPT; ++q) {
       if (q < uy + UXQ) {
@@ -172,15 +178,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
 #pragma unroll
     for (int j = 0; j < PJ; ++j) acc[i][j] = acc_t{(R)0, (R)0, (R)0, (R)0};
 
-  int64_t chunk = blockIdx.x;
-  if (chunk < a.nchunks) load_chunk(chunk);
   const int fr = lane & 15, fk = lane >> 4;
-  for (; chunk < a.nchunks; chunk += gridDim.x) {
-    __syncthreads();                 // previous MFMA phase has finished reading the tile
-    store_chunk();
-    __syncthreads();
-    const int64_t next = chunk + gridDim.x;
-    if (next < a.nchunks) load_chunk(next);   // in flight during the MFMA phase
+  auto mfma_phase = [&]() {
     const int rbase = wave * (ROWS / 4);
 #pragma unroll 4
     for (int ks = 0; ks < ROWS / 16; ++ks) {
@@ -199,6 +198,81 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
           if (same_panel && i > j) continue;
           acc[i][j] = M::run(fa[i], fb[j], acc[i][j]);
         }
+    }
+  };
+
+  if constexpr (MODE == 0) {
+    int64_t chunk = blockIdx.x;
+    if (chunk < a.nchunks) load_chunk(chunk);
+    for (; chunk < a.nchunks; chunk += gridDim.x) {
+      __syncthreads();                 // previous MFMA phase has finished reading the tile
+      store_chunk(regs);
+      __syncthreads();
+      const int64_t next = chunk + gridDim.x;
+      if (next < a.nchunks) load_chunk(next);   // in flight during the MFMA phase
+      mfma_phase();
+    }
+  } else {
+    constexpr int NQ = (MODE == 2 ? 0 : UYQ) + UXQ;       // 16-byte loads per thread and chunk
+    vec_t regs2[UPT];
+    auto load_full = [&](int64_t chunk, vec_t (&r)[UPT]) {
+      const int64_t row0 = chunk * ROWS;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r[q] = *reinterpret_cast<const vec_t *>(piece_ptr(q, row0));
+    };
+    const int64_t nfull = a.n / ROWS;                     // chunks with all ROWS rows
+    const int64_t G = gridDim.x;
+    int64_t c = blockIdx.x;
+    if (c + 3 * G < nfull) {
+      // (the loads in front of the loop are unconditional on this path: a conditional one would
+      // make the compiler wait for both register sets at the first LDS write of the loop)
+      load_full(c, regs);
+      __builtin_amdgcn_sched_barrier(0);                  // keep the issue order: regs first
+      load_full(c + G, regs2);
+      __builtin_amdgcn_sched_barrier(0);
+      for (; c + 3 * G < nfull; c += 2 * G) {             // both prefetch targets exist: no branches inside
+        __syncthreads();
+        store_chunk(regs);
+        __syncthreads();
+        load_full(c + 2 * G, regs);
+        mfma_phase();
+        __syncthreads();
+        store_chunk(regs2);
+        __syncthreads();
+        load_full(c + 3 * G, regs2);
+        mfma_phase();
+      }
+    } else {
+      if (c < nfull) load_full(c, regs);
+      if (c + G < nfull) load_full(c + G, regs2);
+    }
+    // at most three full chunks left: regs holds c, regs2 holds c + G
+    if (c < nfull) {
+      __syncthreads();
+      store_chunk(regs);
+      __syncthreads();
+      if (c + 2 * G < nfull) load_full(c + 2 * G, regs);
+      mfma_phase();
+    }
+    if (c + G < nfull) {
+      __syncthreads();
+      store_chunk(regs2);
+      __syncthreads();
+      mfma_phase();
+    }
+    if (c + 2 * G < nfull) {
+      __syncthreads();
+      store_chunk(regs);
+      __syncthreads();
+      mfma_phase();
+    }
+    // the one chunk with fewer than ROWS rows goes to the workgroup whose turn it is
+    if (nfull < a.nchunks && nfull % G == blockIdx.x) {
+      load_chunk(nfull);
+      __syncthreads();
+      store_chunk(regs);
+      __syncthreads();
+      mfma_phase();
     }
   }
 
@@ -271,12 +345,12 @@ __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int 
 }
 
 // Resident workgroups per CU for one instantiation (registers + LDS), asked once.
-template <int DT, int PI, int PJ, bool ALIGNED>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE>
 static int gram_blocks_per_cu() {
   static int cached = 0;
   if (cached == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED>, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE>, 256, 0) != hipSuccess ||
         nb < 1)
       nb = 1;
     cached = nb > 8 ? 8 : nb;
@@ -292,7 +366,7 @@ static inline int pick_tiles(int v) {   // 16x16 tiles per panel side: 1, 2 or 4
   return 4;
 }
 
-template <int DT, int PI, int PJ, bool ALIGNED>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE>
 static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, void *d_out) {
   using R = typename DType<DT>::R;
   Context &c = ctx();
@@ -300,14 +374,14 @@ static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, vo
   const int npanels = npi * npj;
   // the grid is sized to what is resident at once: every workgroup strides over the row
   // chunks, so a second, partially filled round of workgroups would only add a tail
-  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED>() / npanels;
+  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE>() / npanels;
   if (nbx < 1) nbx = 1;
   if (nbx > a.nchunks) nbx = a.nchunks;
   const size_t part_bytes = sizeof(R) * VY * VX;
   while (nbx > 1 && (size_t)nbx * npanels * part_bytes > kWorkspaceBytes) nbx /= 2;
   RLH_REQUIRE((size_t)nbx * npanels * part_bytes <= kWorkspaceBytes,
               "rlh_gram: %lld x %lld result exceeds the reduction workspace", (long long)my, (long long)mx);
-  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED>), dim3((unsigned)nbx, (unsigned)npanels), dim3(256), 0,
+  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE>), dim3((unsigned)nbx, (unsigned)npanels), dim3(256), 0,
                      c.stream, a);
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
@@ -333,10 +407,22 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   a.npj = npj; a.nchunks = (n + ROWS - 1) / ROWS; a.partials = c.work;
   const int64_t es = dtype_size(DT);
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
+  // kernel variant: see gram_kernel (RLH_GRAM_PIPE=0 forces the general loop: tunable)
+  // measured at n = 10^7, m = 32 fp64: the two-chunk pipeline gains 5 % on the self-Gram
+  // (0.50 -> 0.475 ms) and nothing on the two-operand Gram (0.885 vs 0.868 ms in sustained use), so
+  // the latter keeps the general loop unless RLH_GRAM_PIPE=2
+  static const int pipe = getenv("RLH_GRAM_PIPE") ? atoi(getenv("RLH_GRAM_PIPE")) : 1;
+  const int mode = (!aligned || pipe == 0) ? 0
+                   : (!a.same ? (pipe >= 2 ? 1 : 0) : ((npi == 1 && npj == 1 && PI == PJ) ? 2 : 0));
 #define RLH_GRAM_CASE(pi, pj)                                                              \
-  if (PI == pi && PJ == pj)                                                                \
-    return aligned ? gram_launch<DT, pi, pj, true>(a, npi, npj, my, mx, d_out)             \
-                   : gram_launch<DT, pi, pj, false>(a, npi, npj, my, mx, d_out);
+  if (PI == pi && PJ == pj) {                                                              \
+    if constexpr (pi * pj <= 4)       /* two register sets of a larger panel do not fit */ \
+      if (mode == 1) return gram_launch<DT, pi, pj, true, 1>(a, npi, npj, my, mx, d_out);  \
+    if constexpr (pi == pj && pi <= 2)                                                     \
+      if (mode == 2) return gram_launch<DT, pi, pj, true, 2>(a, npi, npj, my, mx, d_out);  \
+    return aligned ? gram_launch<DT, pi, pj, true, 0>(a, npi, npj, my, mx, d_out)          \
+                   : gram_launch<DT, pi, pj, false, 0>(a, npi, npj, my, mx, d_out);        \
+  }
   RLH_GRAM_CASE(1, 1) RLH_GRAM_CASE(1, 2) RLH_GRAM_CASE(1, 4)
   RLH_GRAM_CASE(2, 1) RLH_GRAM_CASE(2, 2) RLH_GRAM_CASE(2, 4)
   RLH_GRAM_CASE(4, 1) RLH_GRAM_CASE(4, 2) RLH_GRAM_CASE(4, 4)
