@@ -310,16 +310,26 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
     const int64_t row = b * kWellRows + tid;
     // the row's entries: registers for the whole block of vectors (slots past the block's width
     // read the next block's entries -- the arrays are padded -- and are zeroed)
+    // Positions: one register per entry holding the byte offset, or (PACK: 32 slots of an 8-byte
+    // type, where 32 more registers would spill) two 16-bit positions per register, unpacked at use.
+    constexpr bool PACK = WMAX * sizeof(T) >= 256;
     T v[WMAX];
-    unsigned ixb[WMAX];                       // byte offset of the entry's column in a staged vector
+    unsigned ixb[PACK ? WMAX / 2 : WMAX];
 #pragma unroll
     for (int t = 0; t < WMAX; ++t) {
       const int64_t e = (mt.eoff + t) * kWellRows + tid;
       const T val = nt_load(vals + e);
       const unsigned pos_t = __builtin_nontemporal_load(idx + e);
       v[t] = t < width ? val : zero_of(T{});
-      ixb[t] = t < width ? pos_t * (unsigned)sizeof(T) : 0u;
+      const unsigned px = t < width ? pos_t : 0u;
+      if constexpr (!PACK) ixb[t] = px * (unsigned)sizeof(T);
+      else if (t & 1) ixb[t / 2] |= px << 16;
+      else ixb[t / 2] = px;
     }
+    auto entry_offset = [&](int t) -> unsigned {       // byte offset of entry t's column in a staged vector
+      if constexpr (!PACK) return ixb[t];
+      else return ((ixb[t / 2] >> (16 * (t & 1))) & 0xffffu) * (unsigned)sizeof(T);
+    };
     // this thread's share of a step's staging: one load moves EPL elements per lane, i.e. EPL
     // consecutive 64-column groups per wave; slot i of the wave covers groups q .. q + EPL - 1,
     // q = EPL (wave + 16 i), of the step's G (vector cc = q / ng of the step, groups q % ng .. of
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
       else
         scol[i] = gsrc[mt.goff + g + lane / LPG] + (lane % LPG) * EPL;
     }
-    VecU<T, EPL> stA[SLOTS], stB[SLOTS];
+    VecU<T, EPL> stA[SLOTS];
     auto stage_load = [&](int s, VecU<T, EPL> (&st)[SLOTS]) {
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
         asm volatile("" : "+s"(boff));
         T acc = zero_of(T{});
 #pragma unroll
-        for (int t = 0; t < WMAX; ++t) fma_acc(acc, v[t], *reinterpret_cast<const T *>(ldsb + (ixb[t] + boff)));
+        for (int t = 0; t < WMAX; ++t) fma_acc(acc, v[t], *reinterpret_cast<const T *>(ldsb + (entry_offset(t) + boff)));
         if (row < n_rows) {
           if constexpr (!CHEB) {
             nt_store(Y + row + (int64_t)j * ldy, acc);
@@ -397,41 +407,57 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
         boff += (unsigned)F * (unsigned)sizeof(T);
       }
     };
-    // Two register sets: the loads of step s + 2 are issued at the start of step s and written to
-    // the LDS at the end of step s + 1, so they have two steps (and two barriers, which plain
-    // loads survive) to arrive.
-    stage_load(0, stA);
-    stage_load(nsteps > 1 ? 1 : 0, stB);
-    stage_write(0, stA);
-    __syncthreads();
-    int s = 0;
-    for (; s + 3 < nsteps; s += 2) {          // both prefetch targets exist
-      stage_load(s + 2, stA);                 // B holds step s + 1
-      compute(s);
-      stage_write(s + 1, stB);
+    if constexpr (PACK) {
+      // 32 entry slots of an 8-byte type leave room for one register set only: the loads of step
+      // s + 1 are in flight during the arithmetic of step s
+      stage_load(0, stA);
+      stage_write(0, stA);
       __syncthreads();
-      stage_load(s + 3, stB);                 // A holds step s + 2
-      compute(s + 1);
-      stage_write(s + 2, stA);
-      __syncthreads();
-    }
-    const int left = nsteps - s;              // 1, 2 or 3 steps, nothing beyond them to prefetch
-    if (left == 3) {
-      stage_load(s + 2, stA);
-      compute(s);
-      stage_write(s + 1, stB);
-      __syncthreads();
-      compute(s + 1);
-      stage_write(s + 2, stA);
-      __syncthreads();
-      compute(s + 2);
-    } else if (left == 2) {
-      compute(s);
-      stage_write(s + 1, stB);
-      __syncthreads();
-      compute(s + 1);
+      for (int s = 0; s + 1 < nsteps; ++s) {
+        stage_load(s + 1, stA);
+        compute(s);
+        stage_write(s + 1, stA);
+        __syncthreads();
+      }
+      compute(nsteps - 1);
     } else {
-      compute(s);
+      // Two register sets: the loads of step s + 2 are issued at the start of step s and written
+      // to the LDS at the end of step s + 1, so they have two steps (and two barriers, which plain
+      // loads survive) to arrive.
+      VecU<T, EPL> stB[SLOTS];
+      stage_load(0, stA);
+      stage_load(nsteps > 1 ? 1 : 0, stB);
+      stage_write(0, stA);
+      __syncthreads();
+      int s = 0;
+      for (; s + 3 < nsteps; s += 2) {          // both prefetch targets exist
+        stage_load(s + 2, stA);                 // B holds step s + 1
+        compute(s);
+        stage_write(s + 1, stB);
+        __syncthreads();
+        stage_load(s + 3, stB);                 // A holds step s + 2
+        compute(s + 1);
+        stage_write(s + 2, stA);
+        __syncthreads();
+      }
+      const int left = nsteps - s;              // 1, 2 or 3 steps, nothing beyond them to prefetch
+      if (left == 3) {
+        stage_load(s + 2, stA);
+        compute(s);
+        stage_write(s + 1, stB);
+        __syncthreads();
+        compute(s + 1);
+        stage_write(s + 2, stA);
+        __syncthreads();
+        compute(s + 2);
+      } else if (left == 2) {
+        compute(s);
+        stage_write(s + 1, stB);
+        __syncthreads();
+        compute(s + 1);
+      } else {
+        compute(s);
+      }
     }
     __syncthreads();                          // the next block's first stage overwrites the buffers
   }
@@ -476,7 +502,7 @@ template <typename T>
 static int launch_well(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
                        T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
   if (h->well_wmax <= 8) return launch_well_w<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
-  if constexpr (sizeof(T) == 4)               // 32 register slots of a wider type would spill
+  if constexpr (sizeof(T) <= 8)               // 32 register slots of a 16-byte type would spill
     if (h->well_wmax > 16) return launch_well_w<T, 32>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   return launch_well_w<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
@@ -739,7 +765,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     slots += (int64_t)width[b] * kWellRows;
   }
   h->well_ratio = slots > 0 ? (double)staged / (double)slots : 0.0;
-  if (wmax > (sizeof(T) == 4 ? 32 : 16) || gmax > 16 * SMAX) return 0;
+  if (wmax > (sizeof(T) <= 8 ? 32 : 16) || gmax > 16 * SMAX) return 0;
   // measured (profiles/r01_spmm_windowed.txt): at 0.65 staged elements per entry slot (5-point
   // stencil) the windowed kernel is 1.27x faster than the sliced one, at 1.06 (a diagonal
   // matrix) 4 % slower
