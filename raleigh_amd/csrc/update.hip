@@ -18,52 +18,87 @@ namespace rlh {
 
 constexpr int kUnrollK = 4;
 
+static int env_flag(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
 // Two sources: Out = beta*Out + X*Q[0:kpad] + X2*Q[kpad:kpad+k2] in ONE pass (k2 = 0: one source).
-template <typename T, int JT, bool BETA>
+// One lane owns RV consecutive rows (RV * sizeof(T) = 16 bytes when the blocks are 16-byte
+// aligned and the accumulators fit, else 1): every access to X and Out then moves 16 bytes per
+// lane, which the vector-memory path retires at up to twice the bytes per cycle of 8-byte accesses.
+template <typename T, int RV> struct alignas(RV * sizeof(T) >= 16 ? 16 : sizeof(T)) RowVec { T e[RV]; };
+
+template <typename T, int JT, bool BETA, int RV>
 __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__ X, int64_t ldx,
                                                            const T *__restrict__ X2, int64_t ldx2, int k2, int kpad,
                                                            T *__restrict__ Out, int64_t ldo,
                                                            const T *__restrict__ Q, int ldq, int64_t n, int k,
                                                            int m) {
+  using V = RowVec<T, RV>;
   const int j0 = blockIdx.y * JT;
   const int jv = (m - j0) < JT ? (m - j0) : JT;      // valid output columns of this panel
   const T *__restrict__ Qp = Q + j0;
   T *__restrict__ Op = Out + (int64_t)j0 * ldo;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += stride) {
-    T acc[JT];
+  const int64_t stride = (int64_t)gridDim.x * 256 * RV;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV; row < n; row += stride) {
+    const bool whole = row + RV <= n;                // the last lane group of an n not divisible by RV
+    T acc[RV][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-      acc[j] = zero_of(T{});
-      if (BETA && j < jv) acc[j] = Op[row + (int64_t)j * ldo];
-    }
-    for (int i = 0; i < k; i += kUnrollK) {
-      T x[kUnrollK];
 #pragma unroll
-      for (int u = 0; u < kUnrollK; ++u) {
-        const int col = (i + u) < k ? (i + u) : (k - 1);     // Q rows >= k are zero
-        x[u] = X[row + (int64_t)col * ldx];
+      for (int r = 0; r < RV; ++r) acc[r][j] = zero_of(T{});
+      if (BETA && j < jv) {
+        if (whole) {
+          const V o = *reinterpret_cast<const V *>(Op + row + (int64_t)j * ldo);
+#pragma unroll
+          for (int r = 0; r < RV; ++r) acc[r][j] = o.e[r];
+        } else {
+          for (int r = 0; r < RV; ++r)
+            if (row + r < n) acc[r][j] = Op[row + r + (int64_t)j * ldo];
+        }
       }
-#pragma unroll
-      for (int u = 0; u < kUnrollK; ++u)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) fma_acc(acc[j], x[u], Qp[(i + u) * ldq + j]);
     }
-    for (int i = 0; i < k2; i += kUnrollK) {
-      T x[kUnrollK];
+    auto accumulate = [&](const T *__restrict__ S, int64_t lds_, int kk, int qrow0) {
+      for (int i = 0; i < kk; i += kUnrollK) {
+        T x[kUnrollK][RV];
 #pragma unroll
-      for (int u = 0; u < kUnrollK; ++u) {
-        const int col = (i + u) < k2 ? (i + u) : (k2 - 1);
-        x[u] = X2[row + (int64_t)col * ldx2];
+        for (int u = 0; u < kUnrollK; ++u) {
+          const int col = (i + u) < kk ? (i + u) : (kk - 1);     // Q rows >= kk are zero
+          if (whole) {
+            const V xv = *reinterpret_cast<const V *>(S + row + (int64_t)col * lds_);
+#pragma unroll
+            for (int r = 0; r < RV; ++r) x[u][r] = xv.e[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < RV; ++r) x[u][r] = (row + r < n) ? S[row + r + (int64_t)col * lds_] : zero_of(T{});
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnrollK; ++u)
+#pragma unroll
+          for (int j = 0; j < JT; ++j) {
+            const T q = Qp[(qrow0 + i + u) * ldq + j];
+#pragma unroll
+            for (int r = 0; r < RV; ++r) fma_acc(acc[r][j], x[u][r], q);
+          }
       }
-#pragma unroll
-      for (int u = 0; u < kUnrollK; ++u)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) fma_acc(acc[j], x[u], Qp[(kpad + i + u) * ldq + j]);
-    }
+    };
+    accumulate(X, ldx, k, 0);
+    accumulate(X2, ldx2, k2, kpad);
 #pragma unroll
     for (int j = 0; j < JT; ++j)
-      if (j < jv) Op[row + (int64_t)j * ldo] = acc[j];
+      if (j < jv) {
+        if (whole) {
+          V o;
+#pragma unroll
+          for (int r = 0; r < RV; ++r) o.e[r] = acc[r][j];
+          *reinterpret_cast<V *>(Op + row + (int64_t)j * ldo) = o;
+        } else {
+          for (int r = 0; r < RV; ++r)
+            if (row + r < n) Op[row + r + (int64_t)j * ldo] = acc[r][j];
+        }
+      }
   }
 }
 
@@ -79,22 +114,36 @@ template <> struct HostScalar<c64> {
   static c64 mul(const double *a, c64 q) { return c64{a[0] * q.re - a[1] * q.im, a[0] * q.im + a[1] * q.re}; }
 };
 
-template <typename T, int JT>
-static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
-                         int beta, const T *X2 = nullptr, int64_t ldx2 = 0, int k2 = 0, int kpad = 0) {
+template <typename T, int JT, int RV>
+static int launch_update_rv(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
+                            int beta, const T *X2, int64_t ldx2, int k2, int kpad) {
   Context &c = ctx();
-  int64_t nbx = (n + 255) / 256;
+  int64_t nbx = ((n + RV - 1) / RV + 255) / 256;
   const int64_t cap = (int64_t)c.num_cu * 8;
   if (nbx > cap) nbx = cap;
   dim3 grid((unsigned)nbx, (unsigned)((m + JT - 1) / JT));
   if (beta)
-    hipLaunchKernelGGL((block_update_kernel<T, JT, true>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
+    hipLaunchKernelGGL((block_update_kernel<T, JT, true, RV>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
                        Out, ldo, Qd, ldq, n, k, m);
   else
-    hipLaunchKernelGGL((block_update_kernel<T, JT, false>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
+    hipLaunchKernelGGL((block_update_kernel<T, JT, false, RV>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
                        Out, ldo, Qd, ldq, n, k, m);
   RLH_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, int JT>
+static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
+                         int beta, const T *X2 = nullptr, int64_t ldx2 = 0, int k2 = 0, int kpad = 0) {
+  // 16-byte row groups where RV * JT accumulators of T fit (<= 128 registers) and every block is
+  // 16-byte aligned (RLH_UPDATE_RV=0: one row per lane, tunable)
+  constexpr int RVMAX = 16 / (int)sizeof(T);
+  if constexpr (RVMAX > 1 && RVMAX * JT * sizeof(T) <= 512) {
+    static const int rv = env_flag("RLH_UPDATE_RV", 1);
+    if (rv && aligned16(X, ldx, sizeof(T)) && aligned16(Out, ldo, sizeof(T)) && (!X2 || k2 == 0 || aligned16(X2, ldx2, sizeof(T))))
+      return launch_update_rv<T, JT, RVMAX>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad);
+  }
+  return launch_update_rv<T, JT, 1>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad);
 }
 
 template <int DT>
@@ -271,16 +320,34 @@ __global__ __launch_bounds__(256) void scale_cols_kernel(T *__restrict__ X, int6
 
 // Copies columns as raw words of W bytes (16 when everything is 16-byte aligned, else the
 // element's real size); ind == nullptr copies column j to column j.
+// `tail4` 4-byte words follow the n_w whole words of a column (a column of an odd number of
+// 8-byte elements still moves as 16-byte words plus two dwords).  16-byte words go through
+// non-temporal loads and stores (measured +3-6 % on a 2.5 GB block: 5.15-5.25 -> 5.30-5.55 TB/s; the
+// same hint on the block-update stores changed nothing).
 template <typename W>
 __global__ __launch_bounds__(256) void copy_cols_kernel(const W *__restrict__ X, int64_t ldx_w, W *__restrict__ Y,
                                                         int64_t ldy_w, const int64_t *__restrict__ ind,
-                                                        int64_t n_w) {
+                                                        int64_t n_w, int tail4, int nt) {
   const int col = blockIdx.y;
   const int64_t src = ind ? ind[col] : col;
   const W *x = X + src * ldx_w;
   W *y = Y + (int64_t)col * ldy_w;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_w; r += stride) y[r] = x[r];
+  if constexpr (sizeof(W) == 16) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *xv = reinterpret_cast<const u32x4 *>(x);
+    u32x4 *yv = reinterpret_cast<u32x4 *>(y);
+    if (nt) {
+      for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_w; r += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(xv + r), yv + r);
+    } else {
+      for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_w; r += stride) yv[r] = xv[r];
+    }
+  } else {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_w; r += stride) y[r] = x[r];
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail4)
+    reinterpret_cast<uint32_t *>(y + n_w)[threadIdx.x] = reinterpret_cast<const uint32_t *>(x + n_w)[threadIdx.x];
 }
 
 template <typename R>
@@ -424,22 +491,22 @@ static int copy_cols_impl(int dtype, int64_t n, int64_t m, const int64_t *ind, c
   if (ind) {
     if (int rc = stage_coeffs<int64_t>(m, [&](int64_t i) { return ind[i]; }, &slot, &indd)) return rc;
   }
-  const bool al = aligned16(X, ldx, es) && aligned16(Y, ldy, es) && ((n * es) % 16 == 0);
+  const bool al = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
   if (al) {
     typedef struct alignas(16) { uint32_t w[4]; } W16;
     const int64_t nw = n * es / 16;
     dim3 grid(row_blocks(nw, m), (unsigned)m);
     hipLaunchKernelGGL((copy_cols_kernel<W16>), grid, dim3(256), 0, ctx().stream, (const W16 *)X, ldx * es / 16,
-                       (W16 *)Y, ldy * es / 16, indd, nw);
+                       (W16 *)Y, ldy * es / 16, indd, nw, (int)((n * es % 16) / 4), env_flag("RLH_COPY_NT", 1));
   } else if (es % 8 == 0) {
     const int64_t nw = n * es / 8;
     dim3 grid(row_blocks(nw, m), (unsigned)m);
     hipLaunchKernelGGL((copy_cols_kernel<uint64_t>), grid, dim3(256), 0, ctx().stream, (const uint64_t *)X,
-                       ldx * es / 8, (uint64_t *)Y, ldy * es / 8, indd, nw);
+                       ldx * es / 8, (uint64_t *)Y, ldy * es / 8, indd, nw, 0, 0);
   } else {
     dim3 grid(row_blocks(n, m), (unsigned)m);
     hipLaunchKernelGGL((copy_cols_kernel<uint32_t>), grid, dim3(256), 0, ctx().stream, (const uint32_t *)X, ldx,
-                       (uint32_t *)Y, ldy, indd, n);
+                       (uint32_t *)Y, ldy, indd, n, 0, 0);
   }
   RLH_HIP(hipGetLastError());
   if (slot >= 0) return ring_release(slot);
