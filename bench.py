@@ -151,8 +151,8 @@ def solve_ten(side, comm):
             def apply(self, x, y):
                 self.csr.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
 
-            def cheb_step(self, d, r, dn, y, alpha, beta):
-                self.csr.cheb_step_ptr(d.nvec(), d, r, dn, y, alpha, beta)
+            def cheb_step(self, y, p, b, cy, cp, cb):
+                self.csr.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
         op, op32, vectors = Op(np.float64), Op(np.float32), None
     else:
         from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix, partition

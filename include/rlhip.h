@@ -175,13 +175,14 @@ int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per
  * single GPU: n_own = n_cols, H = NULL. */
 int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own,
              const void *H, int64_t ldh, void *Y, int64_t ldy);
-/* One step of the Chebyshev semi-iteration fused with the operator application (device
- * polynomial preconditioner): with t = A*D, per row and vector
- *   R -= t;  Dn = alpha*D + beta*R;  Y += Dn
- * in one pass (A square in the own rows; D, R, Dn, Y distinct blocks). */
-int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *D, int64_t ldd, int64_t n_own,
-                  const void *H, int64_t ldh, void *R, int64_t ldr, void *Dn, int64_t lddn,
-                  void *Y, int64_t ldy, double alpha, double beta);
+/* One step of the Chebyshev semi-iteration (three-term form) fused with the operator
+ * application (device polynomial preconditioner): per row and vector
+ *   P = cy*Y + cp*P + cb*(B - A*Y)
+ * in one pass: Y = y_k (gathered, read only), P = y_{k-1} on entry and y_{k+1} on return
+ * (updated in place), B the right-hand side.  A square in the own rows; P distinct from Y, B. */
+int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_own,
+                  const void *H, int64_t ldh, void *P, int64_t ldp, const void *B, int64_t ldb,
+                  double cy, double cp, double cb);
 /* Packs rows for the halo exchange: Out[i, j] = X[idx[i], j], i < nidx, j < m;
  * idx: DEVICE int64 (built once per operator). */
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m,

@@ -63,7 +63,7 @@ SIGNATURES = {
                      ctypes.POINTER(_i64)],
     'rlh_csr_layout': [_p, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
     'rlh_spmm': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64],
-    'rlh_spmm_cheb': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double,
+    'rlh_spmm_cheb': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double, ctypes.c_double,
                       ctypes.c_double],
     'rlh_dense_apply': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64],
     'rlh_timer_start': [],

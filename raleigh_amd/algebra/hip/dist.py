@@ -359,10 +359,11 @@ class ShardedSparseMatrix:
         halo_ptr, ldh = self._exchange_halo(x)
         self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh)
 
-    def cheb_step(self, d, r, dn, y, alpha, beta):
-        """Fused step of the Chebyshev semi-iteration on row-sharded blocks (one halo exchange of d)."""
-        halo_ptr, ldh = self._exchange_halo(d)
-        self._op.cheb_step_ptr(d.nvec(), d, r, dn, y, alpha, beta, halo_ptr, ldh)
+    def cheb_step(self, y, p, b, cy, cp, cb):
+        """Fused step of the three-term Chebyshev semi-iteration on row-sharded blocks
+        (p = cy y + cp p + cb (b - A y), one halo exchange of y)."""
+        halo_ptr, ldh = self._exchange_halo(y)
+        self._op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb, halo_ptr, ldh)
 
 class ShardedDenseMatrix:
     """Dense operator whose ROWS are distributed over the ranks (BASELINE configs 2/4: the PCA

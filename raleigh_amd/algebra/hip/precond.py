@@ -39,38 +39,48 @@ class ChebyshevPreconditioner:
         self._work = None
 
     def apply(self, x, y):
+        """y = p(A) x by the three-term Chebyshev semi-iteration for A u = x from u_0 = 0:
+        u_1 = x / theta,  u_{k+1} = u_k + rho_k rho_{k-1} (u_k - u_{k-1}) + (2 rho_k / delta) (x - A u_k).
+        u_{k+1} overwrites u_{k-1} (only its own row is needed), so two blocks ping-pong and a
+        fused step reads u_k, u_{k-1}, x and writes u_{k+1} (`cheb_step`)."""
         m = x.nvec()
+        nwork = 3 if self._low else 2
         if self._work is None or self._work[0].nvec() < m or self._work[0].dimension() != x.dimension():
             dt = None
             if self._low:
                 dt = np.complex64 if x.is_complex() else np.float32
-            self._work = [x.new_vectors(m, data_type=dt) for _ in range(5 if self._low else 3)]
+            self._work = [x.new_vectors(m, data_type=dt) for _ in range(nwork)]
         for v in self._work:
             v.select(m)
-        r, d, t = self._work[:3]
         if self._low:
-            xin, yout = self._work[3], self._work[4]
-            x.convert_to(xin)
+            b, ua, ub = self._work
+            x.convert_to(b)
         else:
-            xin, yout = x, y
+            b = x
+            # the last step must land in y: with an even number of steps u_1 starts in y
+            steps = self._degree - 1
+            ua, ub = (y, self._work[0]) if steps % 2 == 0 else (self._work[0], y)
+            t = self._work[1]
         theta, delta = 0.5 * (self._hi + self._lo), 0.5 * (self._hi - self._lo)
         sigma1 = theta / delta
         rho = 1.0 / sigma1
-        xin.copy(r)                                 # r = x - A*0
-        d.lincomb(1.0 / theta, xin, 0.0, xin)       # d = r / theta
-        d.copy(yout)                                # y = d
         fused = hasattr(self._op, 'cheb_step')
+        if not fused and self._low:
+            raise ValueError('low-precision evaluation needs an operator with cheb_step')
+        ua.lincomb(1.0 / theta, b, 0.0, b)          # u_1 = x / theta
+        if self._degree > 1:
+            ub.lincomb(0.0, b, 0.0, b)              # u_0 = 0 (a defined value: 0 * garbage could be NaN)
         for _ in range(self._degree - 1):
             rho_new = 1.0 / (2.0 * sigma1 - rho)
-            if fused:       # r -= A d; dn = a d + b r; y += dn -- one pass, dn in the spare block
-                self._op.cheb_step(d, r, t, yout, rho_new * rho, 2.0 * rho_new / delta)
-                d, t = t, d
+            c, cb = rho_new * rho, 2.0 * rho_new / delta
+            if fused:       # ub = (1 + c) ua - c ub + cb (b - A ua) in one pass: u_{k+1} over u_{k-1}
+                self._op.cheb_step(ua, ub, b, 1.0 + c, -c, cb)
             else:
-                self._op.apply(d, t)
-                r.add(t, -1.0)                      # r -= A d
-                d.lincomb(rho_new * rho, d, 2.0 * rho_new / delta, r)
-                yout.add(d, 1.0)
+                self._op.apply(ua, t)               # t = A u_k
+                t.lincomb(-cb, t, cb, b)            # t = cb (b - A u_k)
+                ub.lincomb(-c, ub, 1.0, t)
+                ub.add(ua, 1.0 + c)
+            ua, ub = ub, ua
             rho = rho_new
-        self._work[:3] = [r, d, t]
         if self._low:
-            yout.convert_to(y)
+            ua.convert_to(y)

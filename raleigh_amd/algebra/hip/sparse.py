@@ -74,11 +74,11 @@ class CsrOperator:
     def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0):
         _lib.check(_lib.lib().rlh_spmm(self._h, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
 
-    def cheb_step_ptr(self, m, d, r, dn, y, alpha, beta, halo_ptr=None, ldh=0):
-        """r -= A d; dn = alpha d + beta r; y += dn in one pass (d, r, dn, y: Vectors windows)."""
-        _lib.check(_lib.lib().rlh_spmm_cheb(self._h, m, d.data_ptr(), d.ld(), self._n_own, halo_ptr, ldh,
-                                            r.data_ptr(), r.ld(), dn.data_ptr(), dn.ld(), y.data_ptr(), y.ld(),
-                                            float(alpha), float(beta)))
+    def cheb_step_ptr(self, m, y, p, b, cy, cp, cb, halo_ptr=None, ldh=0):
+        """p = cy y + cp p + cb (b - A y) in one pass (y, p, b: Vectors windows; p updated in place)."""
+        _lib.check(_lib.lib().rlh_spmm_cheb(self._h, m, y.data_ptr(), y.ld(), self._n_own, halo_ptr, ldh,
+                                            p.data_ptr(), p.ld(), b.data_ptr(), b.ld(),
+                                            float(cy), float(cp), float(cb)))
 
 
 class SparseSymmetricMatrix:
@@ -113,9 +113,9 @@ class SparseSymmetricMatrix:
             raise ValueError('Numbers of input and output vectors differ')
         self.__op.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
 
-    def cheb_step(self, d, r, dn, y, alpha, beta):
-        """Fused step of the Chebyshev semi-iteration: r -= A d; dn = alpha d + beta r; y += dn."""
-        self.__op.cheb_step_ptr(d.nvec(), d, r, dn, y, alpha, beta)
+    def cheb_step(self, y, p, b, cy, cp, cb):
+        """Fused step of the three-term Chebyshev semi-iteration: p = cy y + cp p + cb (b - A y)."""
+        self.__op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
 
 
 class Operator:

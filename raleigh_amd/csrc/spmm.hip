@@ -83,14 +83,17 @@ __device__ __forceinline__ void nt_store(c64 *p, c64 v) {
 //    the SAME slice (tiles_per_block of them), which keeps the set of rows in flight per XCD --
 //    and with it the L2 footprint of the gathered X lines -- small; the matrix entries of the
 //    slice are fetched once per workgroup through L1.
-// Fused Chebyshev step (CHEB): with t = A d the row's results update r -= t, dn = alpha d + beta r,
-// y += dn in the same pass (device polynomial preconditioner); dn must not alias d, which other
-// rows are still gathering.
+// Fused Chebyshev step (CHEB), three-term form: with t = A y the row's results update
+//   p = cy y + cp p + cb (b - t)
+// in the same pass (device polynomial preconditioner: y = y_k, p = y_{k-1} on entry and y_{k+1} on
+// return, b the right-hand side).  p is read and written by the row's own lane only, so it is
+// updated in place; it must not alias y, which other rows are still gathering.  Per element the
+// step reads y, p, b and writes p (the two-term form with a residual and a direction block read
+// three and wrote three).
 template <typename T>
 struct ChebArgs {
-  T *R; int64_t ldr;
-  T *Dn; int64_t lddn;
-  double alpha, beta;
+  const T *B; int64_t ldb;
+  double cy, cp, cb;
 };
 
 __device__ __forceinline__ float  scale_of(double s, float v)  { return (float)s * v; }
@@ -177,13 +180,10 @@ __global__ __launch_bounds__(256, (JT * TT >= 64 ? 1 : 2)) void sell_spmm_kernel
           for (int j = 0; j < JT; ++j)
             if (j < jv) {
               const int64_t jc = j0 + j;
-              T *rp = cheb.R + row + jc * cheb.ldr;
-              const T rr = sub_of(*rp, acc[j]);                               // r -= A d
-              const T dn = add_of(scale_of(cheb.alpha, Xp[row + (int64_t)j * ldx]), scale_of(cheb.beta, rr));
-              *rp = rr;
-              cheb.Dn[row + jc * cheb.lddn] = dn;                             // dn = alpha d + beta r
-              T *yp = Yp + row + (int64_t)j * ldy;
-              *yp = add_of(*yp, dn);                                          // y += dn
+              T *pp = Yp + row + (int64_t)j * ldy;
+              const T res = sub_of(cheb.B[row + jc * cheb.ldb], acc[j]);      // b - A y
+              *pp = add_of(add_of(scale_of(cheb.cy, Xp[row + (int64_t)j * ldx]), scale_of(cheb.cp, *pp)),
+                           scale_of(cheb.cb, res));
             }
         }
       }
@@ -395,13 +395,10 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
           if constexpr (!CHEB) {
             nt_store(Y + row + (int64_t)j * ldy, acc);
           } else {
-            T *rp = cheb.R + row + (int64_t)j * cheb.ldr;
-            const T rr = sub_of(*rp, acc);                                      // r -= A d
-            const T dn = add_of(scale_of(cheb.alpha, X[row + (int64_t)j * ldx]), scale_of(cheb.beta, rr));
-            *rp = rr;
-            cheb.Dn[row + (int64_t)j * cheb.lddn] = dn;                         // dn = alpha d + beta r
-            T *yp = Y + row + (int64_t)j * ldy;
-            *yp = add_of(*yp, dn);                                              // y += dn
+            T *pp = Y + row + (int64_t)j * ldy;
+            const T res = sub_of(cheb.B[row + (int64_t)j * cheb.ldb], acc);     // b - A y
+            *pp = add_of(add_of(scale_of(cheb.cy, X[row + (int64_t)j * ldx]), scale_of(cheb.cp, *pp)),
+                         scale_of(cheb.cb, res));
           }
         }
         boff += (unsigned)F * (unsigned)sizeof(T);
@@ -509,14 +506,14 @@ static int launch_well(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int
 
 template <int DT>
 static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, int64_t n_own, const void *H_,
-                     int64_t ldh, void *Y_, int64_t ldy, void *R_ = nullptr, int64_t ldr = 0, void *Dn_ = nullptr,
-                     int64_t lddn = 0, double alpha = 0.0, double beta = 0.0) {
+                     int64_t ldh, void *Y_, int64_t ldy, const void *B_ = nullptr, int64_t ldb = 0, double cy = 0.0,
+                     double cp = 0.0, double cb = 0.0) {
   using T = typename DType<DT>::T;
   constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
   const T *X = (const T *)X_, *H = (const T *)H_;
   T *Y = (T *)Y_;
-  ChebArgs<T> cargs{(T *)R_, ldr, (T *)Dn_, lddn, alpha, beta};
-  const ChebArgs<T> *cheb = R_ ? &cargs : nullptr;
+  ChebArgs<T> cargs{(const T *)B_, ldb, cy, cp, cb};
+  const ChebArgs<T> *cheb = B_ ? &cargs : nullptr;
   if (h->well_blocks > 0) return launch_well<T>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   static const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
   if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
@@ -949,24 +946,23 @@ int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own, 
   return 1;
 }
 
-int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *D, int64_t ldd, int64_t n_own, const void *H, int64_t ldh,
-                  void *R, int64_t ldr, void *Dn, int64_t lddn, void *Y, int64_t ldy, double alpha, double beta) {
+int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_own, const void *H, int64_t ldh,
+                  void *P, int64_t ldp, const void *B, int64_t ldb, double cy, double cp, double cb) {
   if (int rc = require_ready()) return rc;
   RLH_REQUIRE(h != nullptr, "rlh_spmm_cheb: null handle");
   RLH_REQUIRE(m >= 0, "rlh_spmm_cheb: negative block size");
   if (m == 0 || h->n_rows == 0) return 0;
-  RLH_REQUIRE(D && R && Dn && Y, "rlh_spmm_cheb: null block pointer");
+  RLH_REQUIRE(Y && P && B, "rlh_spmm_cheb: null block pointer");
   RLH_REQUIRE(h->n_rows <= n_own && n_own <= h->n_cols, "rlh_spmm_cheb: the operator block must be square in its own rows");
   RLH_REQUIRE(n_own == h->n_cols || H, "rlh_spmm_cheb: halo block missing for columns >= n_own");
-  RLH_REQUIRE(ldd >= n_own && ldr >= h->n_rows && lddn >= h->n_rows && ldy >= h->n_rows &&
-                  (!H || ldh >= h->n_cols - n_own),
+  RLH_REQUIRE(ldy >= n_own && ldp >= h->n_rows && ldb >= h->n_rows && (!H || ldh >= h->n_cols - n_own),
               "rlh_spmm_cheb: leading dimension smaller than the operator size");
-  RLH_REQUIRE(Dn != D && Dn != R && Dn != Y && D != R && D != Y && R != Y, "rlh_spmm_cheb: the four blocks must be distinct");
+  RLH_REQUIRE(P != Y && P != B, "rlh_spmm_cheb: P is updated in place and must not alias Y or B");
   switch (h->dtype) {
-    case RLH_S: return spmm_impl<RLH_S>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
-    case RLH_D: return spmm_impl<RLH_D>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
-    case RLH_C: return spmm_impl<RLH_C>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
-    case RLH_Z: return spmm_impl<RLH_Z>(h, m, D, ldd, n_own, H, ldh, Y, ldy, R, ldr, Dn, lddn, alpha, beta);
+    case RLH_S: return spmm_impl<RLH_S>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_D: return spmm_impl<RLH_D>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_C: return spmm_impl<RLH_C>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_Z: return spmm_impl<RLH_Z>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
   }
   return 1;
 }

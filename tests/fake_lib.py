@@ -308,23 +308,19 @@ class FakeLib:
         _block(Y, c.code, nr, m, ldy)[:, :] = (c.mat @ x.T).T
         return 0
 
-    def rlh_spmm_cheb(self, h, m, D, ldd, n_own, H, ldh, R, ldr, Dn, lddn, Y, ldy, alpha, beta):
+    def rlh_spmm_cheb(self, h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb):
         self._count('spmm_cheb')
         c = self._csr[_addr(h)]
         nr, ncol = c.mat.shape
         if m == 0 or nr == 0:
             return 0
         x = np.zeros((m, ncol), dtype=_DT[c.code])
-        x[:, :n_own] = _block(D, c.code, n_own, m, ldd)
+        x[:, :n_own] = _block(Y, c.code, n_own, m, ldy)
         if ncol > n_own:
             x[:, n_own:] = _block(H, c.code, ncol - n_own, m, ldh)
         t = (c.mat @ x.T).T
-        r = _block(R, c.code, nr, m, ldr)
-        r[:, :] = r - t
-        dn = _block(Dn, c.code, nr, m, lddn)
-        dn[:, :] = alpha * _block(D, c.code, nr, m, ldd) + beta * r
-        y = _block(Y, c.code, nr, m, ldy)
-        y[:, :] = y + dn
+        pv = _block(P, c.code, nr, m, ldp)
+        pv[:, :] = cy * _block(Y, c.code, nr, m, ldy) + cp * pv + cb * (_block(B, c.code, nr, m, ldb) - t)
         return 0
 
     def rlh_dense_apply(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy):

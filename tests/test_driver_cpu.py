@@ -231,23 +231,19 @@ def test_device_chebyshev_preconditioner():
 
 
 def test_fused_chebyshev_step_equals_unfused():
-    """rlh_spmm_cheb (r -= A d; dn = a d + b r; y += dn) against the same step from apply/add/lincomb."""
+    """rlh_spmm_cheb (p = cy y + cp p + cb (b - A y), p in place) against the same step written out."""
     from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
     from oracle.sparse import lap3d
     A = lap3d(9, 8, 7, 1.0, 1.01, 1.02)
     n = A.shape[0]
     rng = np.random.default_rng(3)
-    d0, r0, y0 = (rng.standard_normal((5, n)) for _ in range(3))
+    y0, p0, b0 = (rng.standard_normal((5, n)) for _ in range(3))
     op = SparseSymmetricMatrix(A)
-    d, r, y, dn = Vectors(d0.copy()), Vectors(r0.copy()), Vectors(y0.copy()), Vectors(n, 5)
-    op.cheb_step(d, r, dn, y, 0.3, -1.7)
-    t = (A @ d0.T).T
-    r1 = r0 - t
-    dn1 = 0.3 * d0 - 1.7 * r1
-    assert np.allclose(r.data(), r1, rtol=1e-13, atol=1e-12)
-    assert np.allclose(dn.data(), dn1, rtol=1e-13, atol=1e-12)
-    assert np.allclose(y.data(), y0 + dn1, rtol=1e-13, atol=1e-12)
-    assert np.array_equal(d.data(), d0)
+    y, p, b = Vectors(y0.copy()), Vectors(p0.copy()), Vectors(b0.copy())
+    op.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+    want = 1.3 * y0 - 0.3 * p0 - 1.7 * (b0 - (A @ y0.T).T)
+    assert np.allclose(p.data(), want, rtol=1e-13, atol=1e-12)
+    assert np.array_equal(y.data(), y0) and np.array_equal(b.data(), b0)
 
 
 def test_mixed_precision_chebyshev_preconditioner():

@@ -281,7 +281,7 @@ def test_more_than_2_31_elements_in_a_block():
 
 @pytest.mark.parametrize('key', ['d', 'z'])
 def test_fused_chebyshev_step(key):
-    """rlh_spmm_cheb: r -= A d; dn = a d + b r; y += dn in one pass, against the oracle."""
+    """rlh_spmm_cheb: p = cy y + cp p + cb (b - A y) in one pass, p in place, against the oracle."""
     from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
     A = lap3d(23, 19, 17, 1.0, 1.01, 1.02)
     if key == 'z':
@@ -290,17 +290,13 @@ def test_fused_chebyshev_step(key):
     n = A.shape[0]
     rng = np.random.default_rng(3)
     m = 21
-    d0, r0, y0 = (rnd((m, n), key, rng) for _ in range(3))
+    y0, p0, b0 = (rnd((m, n), key, rng) for _ in range(3))
     op = SparseSymmetricMatrix(A)
-    d, r, y, dn = Vectors(d0.copy()), Vectors(r0.copy()), Vectors(y0.copy()), Vectors(n, m, data_type=DT[key])
-    op.cheb_step(d, r, dn, y, 0.3, -1.7)
-    t = ops.csr_sym_apply(sp.triu(A, format='csr'), d0)
-    r1 = r0 - t
-    dn1 = 0.3 * d0 - 1.7 * r1
-    assert cases.rel(r.data(), r1) < 1e-13
-    assert cases.rel(dn.data(), dn1) < 1e-13
-    assert cases.rel(y.data(), y0 + dn1) < 1e-13
-    assert np.array_equal(d.data(), d0)
+    y, p, b = Vectors(y0.copy()), Vectors(p0.copy()), Vectors(b0.copy())
+    op.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+    t = ops.csr_sym_apply(sp.triu(A, format='csr'), y0)
+    assert cases.rel(p.data(), 1.3 * y0 - 0.3 * p0 - 1.7 * (b0 - t)) < 1e-13
+    assert np.array_equal(y.data(), y0) and np.array_equal(b.data(), b0)
 
 
 @pytest.mark.parametrize('src,dst', [('d', 's'), ('s', 'd'), ('z', 'c'), ('c', 'z'), ('d', 'd')])
@@ -434,13 +430,10 @@ def test_spmm_layouts_halo_block(spmm_format, key, rows):
     ref = (A @ x.T).T[:, r0:r1]
     tol = 2e-6 if key == 'c' else 1e-13
     assert cases.rel(Y.data(), ref) < tol
-    r_0, y_0 = rnd((m, r1 - r0), key, rng), rnd((m, r1 - r0), key, rng)
-    R, Yc, Dn = Vectors(r_0.copy()), Vectors(y_0.copy()), Vectors(r1 - r0, m, data_type=DT[key])
-    op.cheb_step_ptr(m, X, R, Dn, Yc, 0.7, -0.2, Hb.data_ptr(), Hb.ld())
-    rr = r_0 - ref
-    dn = 0.7 * x[:, r0:r1] - 0.2 * rr
-    assert cases.rel(R.data(), rr) < tol and cases.rel(Dn.data(), dn) < tol
-    assert cases.rel(Yc.data(), y_0 + dn) < tol
+    p_0, b_0 = rnd((m, r1 - r0), key, rng), rnd((m, r1 - r0), key, rng)
+    P, B = Vectors(p_0.copy()), Vectors(b_0.copy())
+    op.cheb_step_ptr(m, X, P, B, 1.7, -0.7, -0.2, Hb.data_ptr(), Hb.ld())
+    assert cases.rel(P.data(), 1.7 * x[:, r0:r1] - 0.7 * p_0 - 0.2 * (b_0 - ref)) < tol
 
 
 @pytest.mark.parametrize('key', ['s', 'd'])
@@ -450,17 +443,13 @@ def test_fused_chebyshev_step_layouts(spmm_format, key):
     n = A.shape[0]
     rng = np.random.default_rng(3)
     m = 10
-    d0, r0, y0 = (rnd((m, n), key, rng) for _ in range(3))
+    y0, p0, b0 = (rnd((m, n), key, rng) for _ in range(3))
     op = SparseSymmetricMatrix(A)
-    d, r, y, dn = Vectors(d0.copy()), Vectors(r0.copy()), Vectors(y0.copy()), Vectors(n, m, data_type=DT[key])
-    op.cheb_step(d, r, dn, y, 0.3, -1.7)
-    t = ops.csr_sym_apply(sp.triu(A, format='csr'), d0)
-    r1 = r0 - t
-    dn1 = 0.3 * d0 - 1.7 * r1
-    tol = 3e-6 if key == 's' else 1e-13
-    assert cases.rel(r.data(), r1) < tol and cases.rel(dn.data(), dn1) < tol
-    assert cases.rel(y.data(), y0 + dn1) < tol
-    assert np.array_equal(d.data(), d0)
+    y, p, b = Vectors(y0.copy()), Vectors(p0.copy()), Vectors(b0.copy())
+    op.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+    t = ops.csr_sym_apply(sp.triu(A, format='csr'), y0)
+    assert cases.rel(p.data(), 1.3 * y0 - 0.3 * p0 - 1.7 * (b0 - t)) < (3e-6 if key == 's' else 1e-13)
+    assert np.array_equal(y.data(), y0)
 
 
 def test_layout_choice(monkeypatch):
