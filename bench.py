@@ -323,7 +323,10 @@ def main():
                       'bytes_breakdown': parts},
            'roofline': roofline}
     if args.solve_side > 0:
-        out['solve'] = solve_ten(args.solve_side, comm)
+        try:
+            out['solve'] = solve_ten(args.solve_side, comm)
+        except Exception as e:      # the headline above is already measured: report, do not lose the line
+            out['solve'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(m)
     if rank == 0:
