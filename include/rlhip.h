@@ -183,6 +183,16 @@ int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own,
 int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_own,
                   const void *H, int64_t ldh, void *P, int64_t ldp, const void *B, int64_t ldb,
                   double cy, double cp, double cb);
+/* The same two operations on a part of the rows, so that a row shard can overlap its halo
+ * exchange with the rows that do not need it: part 1 = the rows whose entries all lie in columns
+ * < n_own (H is not read and may still be in flight), part 2 = the other rows, part 0 = all.
+ * Parts 1 and 2 together write every row exactly once.  (Granularity: the layout's 1024-row blocks;
+ * with the sliced layout part 1 is empty and part 2 is everything.) */
+int rlh_spmm_part(rlh_csr_t h, int part, int64_t m, const void *X, int64_t ldx, int64_t n_own,
+                  const void *H, int64_t ldh, void *Y, int64_t ldy);
+int rlh_spmm_cheb_part(rlh_csr_t h, int part, int64_t m, const void *Y, int64_t ldy, int64_t n_own,
+                       const void *H, int64_t ldh, void *P, int64_t ldp, const void *B, int64_t ldb,
+                       double cy, double cp, double cb);
 /* Packs rows for the halo exchange: Out[i, j] = X[idx[i], j], i < nidx, j < m;
  * idx: DEVICE int64 (built once per operator). */
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m,

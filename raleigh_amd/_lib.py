@@ -65,6 +65,9 @@ SIGNATURES = {
     'rlh_spmm': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64],
     'rlh_spmm_cheb': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double, ctypes.c_double,
                       ctypes.c_double],
+    'rlh_spmm_part': [_p, _int, _i64, _p, _i64, _i64, _p, _i64, _p, _i64],
+    'rlh_spmm_cheb_part': [_p, _int, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double,
+                           ctypes.c_double, ctypes.c_double],
     'rlh_dense_apply': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64],
     'rlh_timer_start': [],
     'rlh_timer_stop': [ctypes.POINTER(ctypes.c_float)],

@@ -320,14 +320,14 @@ class ShardedSparseMatrix:
             self._bufs[key] = (c.buffer(ns * m * es), c.buffer(nr * m * es), c.buffer(nr * m * es))
         return self._bufs[key]
 
-    def _exchange_halo(self, x):
-        """Brings the off-shard rows of x referenced by this rank's rows into one halo block;
-        returns (device pointer, leading dimension) or (None, 0) when nothing is off-shard."""
+    def _start_exchange(self, x):
+        """Packs the rows the peers need and posts the sends / receives; returns what
+        `_finish_exchange` needs, or None when nothing is off-shard."""
         c, L = self._comm, _lib.lib()
         m = x.nvec()
         code, es = x._code, x._es
         if not (self._n_halo > 0 or self._send):
-            return None, 0
+            return None
         sendbuf, recvbuf, halo = self._buffers(m, es)
         ops, soff, roff = [], 0, 0
         for p, didx, cnt in self._send:                   # pack the rows each peer needs
@@ -338,9 +338,18 @@ class ShardedSparseMatrix:
         for p, hs, cnt in self._recv:
             ops.append(c.dist.P2POp(c.dist.irecv, recvbuf[roff:roff + cnt * m * es], p, group=c.group))
             roff += cnt * m * es
-        if ops:
-            for w in c.dist.batch_isend_irecv(ops):
-                w.wait()
+        works = c.dist.batch_isend_irecv(ops) if ops else []
+        return works, recvbuf, halo, m, es
+
+    def _finish_exchange(self, pending):
+        """Waits for the transfers and assembles the halo block; returns (device pointer, leading
+        dimension) or (None, 0)."""
+        if pending is None:
+            return None, 0
+        works, recvbuf, halo, m, es = pending
+        L = _lib.lib()
+        for w in works:
+            w.wait()
         roff = 0
         for p, hs, cnt in self._recv:                     # peer blocks (ld = cnt) -> one halo block (ld = n_halo)
             _lib.check(L.rlh_copy2d(halo.data_ptr() + hs * es, self._n_halo * es,
@@ -350,20 +359,47 @@ class ShardedSparseMatrix:
             return halo.data_ptr(), self._n_halo
         return None, 0
 
+    def _exchange_halo(self, x):
+        """Brings the off-shard rows of x referenced by this rank's rows into one halo block;
+        returns (device pointer, leading dimension) or (None, 0) when nothing is off-shard."""
+        return self._finish_exchange(self._start_exchange(x))
+
+    def _halo_slot(self, x):
+        """The (not yet filled) halo block the interior pass may be handed."""
+        if self._n_halo == 0:
+            return None, 0
+        return self._buffers(x.nvec(), x._es)[2].data_ptr(), self._n_halo
+
     def apply(self, x, y):
         m = x.nvec()
         if m != y.nvec():
             raise ValueError('Numbers of input and output vectors differ')
         if x.dimension() != self._n or y.dimension() != self._n:
             raise ValueError('Matrix and vectors dimensions incompatible')
-        halo_ptr, ldh = self._exchange_halo(x)
-        self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh)
+        # the rows that reference no off-shard column are multiplied while the exchange is in
+        # flight (the transfers run on the communication library's own stream; only `wait`
+        # orders them with the kernels' stream); the other rows follow it
+        pending = self._start_exchange(x)
+        if pending is None:
+            self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
+            return
+        hp, ldh = self._halo_slot(x)
+        self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), hp, ldh, part=1)
+        halo_ptr, ldh = self._finish_exchange(pending)
+        self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh, part=2)
 
     def cheb_step(self, y, p, b, cy, cp, cb):
         """Fused step of the three-term Chebyshev semi-iteration on row-sharded blocks
-        (p = cy y + cp p + cb (b - A y), one halo exchange of y)."""
-        halo_ptr, ldh = self._exchange_halo(y)
-        self._op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb, halo_ptr, ldh)
+        (p = cy y + cp p + cb (b - A y), one halo exchange of y overlapped with the interior rows)."""
+        pending = self._start_exchange(y)
+        if pending is None:
+            self._op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
+            return
+        hp, ldh = self._halo_slot(y)
+        self._op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb, hp, ldh, part=1)
+        halo_ptr, ldh = self._finish_exchange(pending)
+        self._op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb, halo_ptr, ldh, part=2)
+
 
 class ShardedDenseMatrix:
     """Dense operator whose ROWS are distributed over the ranks (BASELINE configs 2/4: the PCA

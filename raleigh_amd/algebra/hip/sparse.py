@@ -71,14 +71,15 @@ class CsrOperator:
         _lib.check(_lib.lib().rlh_csr_layout(self._h, ctypes.byref(lay), ctypes.byref(stored), ctypes.byref(ratio)))
         return ('well' if lay.value == 1 else 'sell'), int(stored.value), float(ratio.value)
 
-    def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0):
-        _lib.check(_lib.lib().rlh_spmm(self._h, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
+    def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0, part=0):
+        """part 0: all rows; 1: the rows that need no halo column; 2: the others (rlh_spmm_part)."""
+        _lib.check(_lib.lib().rlh_spmm_part(self._h, part, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
 
-    def cheb_step_ptr(self, m, y, p, b, cy, cp, cb, halo_ptr=None, ldh=0):
+    def cheb_step_ptr(self, m, y, p, b, cy, cp, cb, halo_ptr=None, ldh=0, part=0):
         """p = cy y + cp p + cb (b - A y) in one pass (y, p, b: Vectors windows; p updated in place)."""
-        _lib.check(_lib.lib().rlh_spmm_cheb(self._h, m, y.data_ptr(), y.ld(), self._n_own, halo_ptr, ldh,
-                                            p.data_ptr(), p.ld(), b.data_ptr(), b.ld(),
-                                            float(cy), float(cp), float(cb)))
+        _lib.check(_lib.lib().rlh_spmm_cheb_part(self._h, part, m, y.data_ptr(), y.ld(), self._n_own, halo_ptr, ldh,
+                                                 p.data_ptr(), p.ld(), b.data_ptr(), b.ld(),
+                                                 float(cy), float(cp), float(cb)))
 
 
 class SparseSymmetricMatrix:

@@ -48,6 +48,14 @@ struct rlh_csr {
   int32_t *well_sched;     // device: block processed at launch position p (-1: none)
   int64_t well_sched_len;
   int well_grid;           // workgroups the schedule was laid out for
+  // split of the blocks by "references a column >= n_own" (overlap of the halo exchange with the
+  // interior rows, rlh_spmm_part): host-side order / largest referenced column per block, and the
+  // two launch orders built on first use for a given n_own
+  std::vector<int32_t> well_order, well_maxcol;
+  int64_t well_split_at;   // n_own the split was built for (-1: none)
+  int32_t *well_sched_part[2];
+  int64_t well_sched_part_len[2];
+  int well_grid_part[2];
   int well_inbounds;       // every staging group lies inside [0, n_cols)
   int well_aligned;        // every staging group starts on a multiple of 4 columns
 };
@@ -461,28 +469,32 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
 }
 
 template <typename T, int WMAX, int EPL>
-static int launch_well_we(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
-                          T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
+static int launch_well_we(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
+                          int64_t ldh, T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
   Context &c = ctx();
-  const int64_t nb = h->well_grid;            // 64-128 KiB of LDS: one workgroup per CU, persistent
+  // launch order: all blocks, or the blocks without / with halo columns (rlh_spmm_part)
+  const int32_t *sched = part == 0 ? h->well_sched : h->well_sched_part[part - 1];
+  const int64_t sched_len = part == 0 ? h->well_sched_len : h->well_sched_part_len[part - 1];
+  const int64_t nb = part == 0 ? h->well_grid : h->well_grid_part[part - 1];   // one workgroup per CU, persistent
+  if (nb == 0) return 0;
   static const int cps_cap = env_int("RLH_SPMM_CPS", 8);       // vectors per step (tunable)
   if (cheb)
     hipLaunchKernelGGL((well_spmm_kernel<T, WMAX, EPL, true>), dim3((unsigned)nb), dim3(1024), 0, c.stream,
                        h->well_meta, h->well_gsrc, h->well_idx, (const T *)h->well_vals, h->n_rows, h->n_cols,
-                       h->well_sched, h->well_sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                       sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
                        cps_cap < 1 ? 1 : cps_cap, *cheb);
   else
     hipLaunchKernelGGL((well_spmm_kernel<T, WMAX, EPL, false>), dim3((unsigned)nb), dim3(1024), 0, c.stream,
                        h->well_meta, h->well_gsrc, h->well_idx, (const T *)h->well_vals, h->n_rows, h->n_cols,
-                       h->well_sched, h->well_sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                       sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
                        cps_cap < 1 ? 1 : cps_cap, ChebArgs<T>{});
   RLH_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T, int WMAX>
-static int launch_well_w(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
-                         T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
+static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
+                         int64_t ldh, T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
   // 16-byte staging loads when every piece is whole: groups inside the column range, and with a
   // halo block no piece across the own / halo boundary (aligned groups, n_own a multiple of the
   // piece); the addresses themselves only need T's alignment
@@ -490,22 +502,24 @@ static int launch_well_w(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, i
   if constexpr (EPL > 1) {
     static const int vec = env_int("RLH_SPMM_VEC", 1);         // 0: 8-byte staging (tunable)
     const bool whole = h->well_inbounds && (H == nullptr || n_own == h->n_cols || (h->well_aligned && n_own % EPL == 0));
-    if (vec && whole) return launch_well_we<T, WMAX, EPL>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+    if (vec && whole) return launch_well_we<T, WMAX, EPL>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   }
-  return launch_well_we<T, WMAX, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  return launch_well_we<T, WMAX, 1>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 
 template <typename T>
-static int launch_well(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
-                       T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
-  if (h->well_wmax <= 8) return launch_well_w<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+static int launch_well(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
+                       int64_t ldh, T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
+  if (h->well_wmax <= 8) return launch_well_w<T, 8>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if constexpr (sizeof(T) <= 8)               // 32 register slots of a 16-byte type would spill
-    if (h->well_wmax > 16) return launch_well_w<T, 32>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
-  return launch_well_w<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+    if (h->well_wmax > 16) return launch_well_w<T, 32>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  return launch_well_w<T, 16>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 
+static int well_split(rlh_csr *h, int64_t n_own);
+
 template <int DT>
-static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, int64_t n_own, const void *H_,
+static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ldx, int64_t n_own, const void *H_,
                      int64_t ldh, void *Y_, int64_t ldy, const void *B_ = nullptr, int64_t ldb = 0, double cy = 0.0,
                      double cp = 0.0, double cb = 0.0) {
   using T = typename DType<DT>::T;
@@ -514,7 +528,12 @@ static int spmm_impl(const rlh_csr *h, int64_t m, const void *X_, int64_t ldx, i
   T *Y = (T *)Y_;
   ChebArgs<T> cargs{(const T *)B_, ldb, cy, cp, cb};
   const ChebArgs<T> *cheb = B_ ? &cargs : nullptr;
-  if (h->well_blocks > 0) return launch_well<T>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if (h->well_blocks > 0) {
+    if (part != 0)
+      if (int rc = well_split(h, n_own)) return rc;
+    return launch_well<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  }
+  if (part == 1) return 0;                    // sliced layout: everything happens in part 2
   static const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
   if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
@@ -603,19 +622,39 @@ static int csr_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, 
 // L2 hit left by the block that owns those rows, instead of a second and third trip over the fabric
 // (speed only: any order gives the same result).  Greedy: a group of 32 is grown from the lowest
 // unscheduled block by repeatedly adding the unscheduled block that overlaps most with the group.
-template <typename WinVec>
-static void well_schedule(const std::vector<WinVec> &wins, int64_t nblocks, int64_t n_rows, int num_cu,
-                          std::vector<int32_t> &sched, int &grid) {
+// position r * grid + 8 i + x  <-  member i of group g = 8 r + x of the ordered block list
+static void well_layout(const std::vector<int32_t> &order, int num_cu, std::vector<int32_t> &sched, int &grid) {
   const int xcds = 8;
   int per_xcd = num_cu / xcds;
   if (per_xcd < 1) per_xcd = 1;
-  if (nblocks <= xcds * per_xcd || env_int("RLH_SPMM_SCHED", 1) == 0) {
-    grid = (int)std::min<int64_t>(nblocks, (int64_t)xcds * per_xcd);
-    sched.resize((size_t)nblocks);
-    for (int64_t b = 0; b < nblocks; ++b) sched[b] = (int32_t)b;
+  const int64_t nb = (int64_t)order.size();
+  if (nb <= (int64_t)xcds * per_xcd) {
+    grid = (int)nb;
+    sched = order;
     return;
   }
   grid = xcds * per_xcd;
+  const int64_t ngroups = (nb + per_xcd - 1) / per_xcd;
+  const int64_t rounds = (ngroups + xcds - 1) / xcds;
+  sched.assign((size_t)(rounds * grid), -1);
+  for (int64_t k = 0; k < nb; ++k) {
+    const int64_t g = k / per_xcd, i = k % per_xcd;
+    sched[(size_t)((g / xcds) * grid + i * xcds + g % xcds)] = order[(size_t)k];
+  }
+}
+
+template <typename WinVec>
+static void well_schedule(const std::vector<WinVec> &wins, int64_t nblocks, int64_t n_rows, int num_cu,
+                          std::vector<int32_t> &order) {
+  const int xcds = 8;
+  int per_xcd = num_cu / xcds;
+  if (per_xcd < 1) per_xcd = 1;
+  order.clear();
+  order.reserve((size_t)nblocks);
+  if (nblocks <= xcds * per_xcd || env_int("RLH_SPMM_SCHED", 1) == 0) {
+    for (int64_t b = 0; b < nblocks; ++b) order.push_back((int32_t)b);
+    return;
+  }
   // overlap graph: weight = rows of block c that block b stages (both directions)
   std::vector<std::vector<std::pair<int32_t, int32_t>>> adj((size_t)nblocks);
   for (int64_t b = 0; b < nblocks; ++b)
@@ -632,8 +671,6 @@ static void well_schedule(const std::vector<WinVec> &wins, int64_t nblocks, int6
     }
   std::vector<char> done((size_t)nblocks, 0);
   std::vector<int64_t> weight((size_t)nblocks, 0);
-  std::vector<int32_t> order;
-  order.reserve((size_t)nblocks);
   int64_t seed = 0;
   while ((int64_t)order.size() < nblocks) {
     std::vector<int32_t> touched;
@@ -660,14 +697,30 @@ static void well_schedule(const std::vector<WinVec> &wins, int64_t nblocks, int6
     }
     for (int32_t c : touched) weight[c] = 0;
   }
-  // group g = 8 r + x, member i  ->  position r * grid + 8 i + x
-  const int64_t ngroups = (nblocks + per_xcd - 1) / per_xcd;
-  const int64_t rounds = (ngroups + xcds - 1) / xcds;
-  sched.assign((size_t)(rounds * grid), -1);
-  for (int64_t k = 0; k < nblocks; ++k) {
-    const int64_t g = k / per_xcd, i = k % per_xcd;
-    sched[(size_t)((g / xcds) * grid + i * xcds + g % xcds)] = order[(size_t)k];
+}
+
+// The two launch orders of rlh_spmm_part for the own / halo boundary n_own: blocks that reference
+// only own columns, and the rest (each keeps the grouped order of the full schedule).
+static int well_split(rlh_csr *h, int64_t n_own) {
+  if (h->well_split_at == n_own) return 0;
+  for (int k = 0; k < 2; ++k) {
+    if (h->well_sched_part[k]) (void)hipFree(h->well_sched_part[k]);
+    h->well_sched_part[k] = nullptr;
+    h->well_sched_part_len[k] = 0;
+    h->well_grid_part[k] = 0;
   }
+  std::vector<int32_t> part[2];
+  for (int32_t b : h->well_order) part[h->well_maxcol[(size_t)b] < n_own ? 0 : 1].push_back(b);
+  for (int k = 0; k < 2; ++k) {
+    if (part[k].empty()) continue;
+    std::vector<int32_t> sched;
+    well_layout(part[k], ctx().num_cu, sched, h->well_grid_part[k]);
+    h->well_sched_part_len[k] = (int64_t)sched.size();
+    RLH_HIP(hipMalloc((void **)&h->well_sched_part[k], sched.size() * sizeof(int32_t)));
+    RLH_HIP(hipMemcpy(h->well_sched_part[k], sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  h->well_split_at = n_own;
+  return 0;
 }
 
 // Host side of the windowed layout.  Returns 0 with h->well_blocks == 0 when the matrix does not
@@ -819,7 +872,10 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     if (gsrc[g] & 3) h->well_aligned = 0;
   }
   std::vector<int32_t> sched;
-  well_schedule(wins, nblocks, n, ctx().num_cu, sched, h->well_grid);
+  well_schedule(wins, nblocks, n, ctx().num_cu, h->well_order);
+  well_layout(h->well_order, ctx().num_cu, sched, h->well_grid);
+  h->well_maxcol.resize((size_t)nblocks);
+  for (int64_t b = 0; b < nblocks; ++b) h->well_maxcol[(size_t)b] = wins[b].back().start + wins[b].back().len - 1;
   h->well_sched_len = (int64_t)sched.size();
   RLH_HIP(hipMalloc((void **)&h->well_sched, sched.size() * sizeof(int32_t)));
   RLH_HIP(hipMemcpy(h->well_sched, sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -865,6 +921,8 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->slice_ptr = nullptr; h->cols = nullptr; h->vals = nullptr;
   h->well_blocks = 0; h->well_meta = nullptr; h->well_gsrc = nullptr; h->well_idx = nullptr; h->well_vals = nullptr;
   h->well_ratio = 0.0; h->well_sched = nullptr; h->well_sched_len = 0; h->well_grid = 0; h->well_inbounds = 0; h->well_aligned = 0;
+  h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
+  h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
   // layout: the windowed one when the matrix qualifies, else the sliced one
   // (RLH_SPMM_FORMAT=sell|well overrides the locality test; read per handle so tests can cover both)
   const char *fmt = getenv("RLH_SPMM_FORMAT");
@@ -903,6 +961,8 @@ int rlh_csr_destroy(rlh_csr_t h) {
     if (h->well_idx) (void)hipFree(h->well_idx);
     if (h->well_vals) (void)hipFree(h->well_vals);
     if (h->well_sched) (void)hipFree(h->well_sched);
+    for (int k = 0; k < 2; ++k)
+      if (h->well_sched_part[k]) (void)hipFree(h->well_sched_part[k]);
   }
   delete h;
   return 0;
@@ -925,10 +985,11 @@ int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per
   return 0;
 }
 
-int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own, const void *H, int64_t ldh, void *Y,
-             int64_t ldy) {
+int rlh_spmm_part(rlh_csr_t h, int part, int64_t m, const void *X, int64_t ldx, int64_t n_own, const void *H,
+                  int64_t ldh, void *Y, int64_t ldy) {
   if (int rc = require_ready()) return rc;
   RLH_REQUIRE(h != nullptr, "rlh_spmm: null handle");
+  RLH_REQUIRE(part >= 0 && part <= 2, "rlh_spmm: part must be 0 (all rows), 1 (interior) or 2 (boundary)");
   RLH_REQUIRE(m >= 0, "rlh_spmm: negative block size");
   if (m == 0 || h->n_rows == 0) return 0;
   RLH_REQUIRE(Y && (X || n_own == 0), "rlh_spmm: null block pointer");
@@ -938,18 +999,24 @@ int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own, 
               "rlh_spmm: leading dimension smaller than the operator size");
   RLH_REQUIRE(X != Y, "rlh_spmm: in-place application is not supported");
   switch (h->dtype) {
-    case RLH_S: return spmm_impl<RLH_S>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-    case RLH_D: return spmm_impl<RLH_D>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-    case RLH_C: return spmm_impl<RLH_C>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
-    case RLH_Z: return spmm_impl<RLH_Z>(h, m, X, ldx, n_own, H, ldh, Y, ldy);
+    case RLH_S: return spmm_impl<RLH_S>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy);
+    case RLH_D: return spmm_impl<RLH_D>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy);
+    case RLH_C: return spmm_impl<RLH_C>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy);
+    case RLH_Z: return spmm_impl<RLH_Z>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy);
   }
   return 1;
 }
 
-int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_own, const void *H, int64_t ldh,
-                  void *P, int64_t ldp, const void *B, int64_t ldb, double cy, double cp, double cb) {
+int rlh_spmm(rlh_csr_t h, int64_t m, const void *X, int64_t ldx, int64_t n_own, const void *H, int64_t ldh, void *Y,
+             int64_t ldy) {
+  return rlh_spmm_part(h, 0, m, X, ldx, n_own, H, ldh, Y, ldy);
+}
+
+int rlh_spmm_cheb_part(rlh_csr_t h, int part, int64_t m, const void *Y, int64_t ldy, int64_t n_own, const void *H,
+                       int64_t ldh, void *P, int64_t ldp, const void *B, int64_t ldb, double cy, double cp, double cb) {
   if (int rc = require_ready()) return rc;
   RLH_REQUIRE(h != nullptr, "rlh_spmm_cheb: null handle");
+  RLH_REQUIRE(part >= 0 && part <= 2, "rlh_spmm_cheb: part must be 0 (all rows), 1 (interior) or 2 (boundary)");
   RLH_REQUIRE(m >= 0, "rlh_spmm_cheb: negative block size");
   if (m == 0 || h->n_rows == 0) return 0;
   RLH_REQUIRE(Y && P && B, "rlh_spmm_cheb: null block pointer");
@@ -959,12 +1026,17 @@ int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_
               "rlh_spmm_cheb: leading dimension smaller than the operator size");
   RLH_REQUIRE(P != Y && P != B, "rlh_spmm_cheb: P is updated in place and must not alias Y or B");
   switch (h->dtype) {
-    case RLH_S: return spmm_impl<RLH_S>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
-    case RLH_D: return spmm_impl<RLH_D>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
-    case RLH_C: return spmm_impl<RLH_C>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
-    case RLH_Z: return spmm_impl<RLH_Z>(h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_S: return spmm_impl<RLH_S>(h, part, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_D: return spmm_impl<RLH_D>(h, part, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_C: return spmm_impl<RLH_C>(h, part, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+    case RLH_Z: return spmm_impl<RLH_Z>(h, part, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
   }
   return 1;
+}
+
+int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_own, const void *H, int64_t ldh,
+                  void *P, int64_t ldp, const void *B, int64_t ldb, double cy, double cp, double cb) {
+  return rlh_spmm_cheb_part(h, 0, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
 }
 
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m, const void *X, int64_t ldx, void *Out,

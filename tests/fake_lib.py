@@ -293,34 +293,53 @@ class FakeLib:
     def rlh_csr_layout(self, h, layout, stored, ratio):
         return 0
 
+    def _rows_of_part(self, c, part, n_own):
+        """Row mask of rlh_spmm_part (granularity here: single rows; the library uses 1024-row blocks)."""
+        nr = c.mat.shape[0]
+        if part == 0:
+            return np.ones(nr, dtype=bool)
+        csr = c.mat.tocsr()
+        far = np.zeros(nr, dtype=bool)
+        rows = np.repeat(np.arange(nr), np.diff(csr.indptr))
+        far[rows[csr.indices >= n_own]] = True
+        return ~far if part == 1 else far
+
     def rlh_spmm(self, h, m, X, ldx, n_own, H, ldh, Y, ldy):
-        self._count('spmm')
+        return self.rlh_spmm_part(h, 0, m, X, ldx, n_own, H, ldh, Y, ldy)
+
+    def rlh_spmm_part(self, h, part, m, X, ldx, n_own, H, ldh, Y, ldy):
+        self._count('spmm' if part == 0 else 'spmm_part%d' % part)
         c = self._csr[_addr(h)]
         nr, ncol = c.mat.shape
         if m == 0 or nr == 0:
             return 0
         x = np.zeros((m, ncol), dtype=_DT[c.code])
         x[:, :n_own] = _block(X, c.code, n_own, m, ldx)
-        if ncol > n_own:
-            if not _addr(H):
-                return self._fail('rlh_spmm: halo block missing for columns >= n_own')
+        if ncol > n_own and part != 1:               # part 1 must not depend on the halo block
             x[:, n_own:] = _block(H, c.code, ncol - n_own, m, ldh)
-        _block(Y, c.code, nr, m, ldy)[:, :] = (c.mat @ x.T).T
+        mask = self._rows_of_part(c, part, n_own)
+        y = _block(Y, c.code, nr, m, ldy)
+        y[:, mask] = ((c.mat @ x.T).T)[:, mask]
         return 0
 
     def rlh_spmm_cheb(self, h, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb):
-        self._count('spmm_cheb')
+        return self.rlh_spmm_cheb_part(h, 0, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb)
+
+    def rlh_spmm_cheb_part(self, h, part, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb):
+        self._count('spmm_cheb' if part != 1 else 'spmm_cheb_part1')
         c = self._csr[_addr(h)]
         nr, ncol = c.mat.shape
         if m == 0 or nr == 0:
             return 0
         x = np.zeros((m, ncol), dtype=_DT[c.code])
         x[:, :n_own] = _block(Y, c.code, n_own, m, ldy)
-        if ncol > n_own:
+        if ncol > n_own and part != 1:
             x[:, n_own:] = _block(H, c.code, ncol - n_own, m, ldh)
         t = (c.mat @ x.T).T
+        mask = self._rows_of_part(c, part, n_own)
         pv = _block(P, c.code, nr, m, ldp)
-        pv[:, :] = cy * _block(Y, c.code, nr, m, ldy) + cp * pv + cb * (_block(B, c.code, nr, m, ldb) - t)
+        new = cy * _block(Y, c.code, nr, m, ldy) + cp * pv + cb * (_block(B, c.code, nr, m, ldb) - t)
+        pv[:, mask] = new[:, mask]
         return 0
 
     def rlh_dense_apply(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy):

@@ -521,3 +521,51 @@ def test_fill_random_large_block_uses_device_generator():
     np.random.seed(3)
     seed = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
     assert np.array_equal(V.data(), ops.uniform_block(seed, n, m, np.float64))
+
+
+@pytest.mark.parametrize('key', ['d', 's'])
+def test_spmm_interior_boundary_parts(spmm_format, key):
+    """rlh_spmm_part / rlh_spmm_cheb_part: part 1 (rows without halo columns) must not depend on
+    the halo block -- it is handed NaNs here -- and parts 1 + 2 together give the full product."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    A = _sym(lap3d(40, 40, 40, 1.0, 1.01, 1.02), key)
+    n = A.shape[0]
+    r0, r1 = 20000, 44001
+    loc = A[r0:r1]
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    n_own_pad = -(-(r1 - r0) // 4) * 4
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(r1 - r0)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr),
+                      shape=(r1 - r0, n_own_pad + len(halo)))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    rng = np.random.default_rng(12)
+    m = 7
+    x = rnd((m, n), key, rng)
+    xo = np.zeros((m, n_own_pad), dtype=DT[key])
+    xo[:, :r1 - r0] = x[:, r0:r1]
+    X, Hgood = Vectors(xo), Vectors(np.ascontiguousarray(x[:, halo]))
+    Hbad = Vectors(np.full((m, len(halo)), np.nan, dtype=DT[key]))
+    Y = Vectors(r1 - r0, m, data_type=DT[key])
+    Y.fill(np.full((m, r1 - r0), 777, dtype=DT[key]))
+    ref = (A @ x.T).T[:, r0:r1]
+    tol = 3e-6 if key == 's' else 1e-13
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hbad.data_ptr(), Hbad.ld(), part=1)
+    y1 = Y.data()
+    done = y1[0] != 777                                   # rows written by part 1
+    assert np.all(np.isfinite(y1[:, done])) and cases.rel(y1[:, done], ref[:, done]) < tol
+    if spmm_format == 'well':
+        assert 0.5 < done.mean() < 1.0                    # most blocks are interior, the shard ends are not
+    else:
+        assert not done.any()                             # sliced layout: everything is left to part 2
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hgood.data_ptr(), Hgood.ld(), part=2)
+    assert cases.rel(Y.data(), ref) < tol
+    # fused Chebyshev step in two parts
+    p0, b0 = rnd((m, r1 - r0), key, rng), rnd((m, r1 - r0), key, rng)
+    P, B = Vectors(p0.copy()), Vectors(b0.copy())
+    op.cheb_step_ptr(m, X, P, B, 1.2, -0.2, 0.4, Hbad.data_ptr(), Hbad.ld(), part=1)
+    op.cheb_step_ptr(m, X, P, B, 1.2, -0.2, 0.4, Hgood.data_ptr(), Hgood.ld(), part=2)
+    assert cases.rel(P.data(), 1.2 * x[:, r0:r1] - 0.2 * p0 + 0.4 * (b0 - ref)) < tol
