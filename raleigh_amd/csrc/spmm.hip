@@ -271,6 +271,17 @@ static int launch_spmm(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int
 template <typename T> struct WellCfg { static constexpr int SMAX = sizeof(T) >= 16 ? 4 : 8; };   // <= 64 KiB per buffer
 constexpr int kWellRows = 1024;
 
+// Exchange within a quad of lanes (DPP quad_perm): CTRL 0xB1 = lane ^ 1, 0x4E = lane ^ 2.
+template <typename T, int CTRL>
+__device__ __forceinline__ T dpp_quad(T v) {
+  constexpr int W = (int)(sizeof(T) / 4);
+  union { T t; int w[W]; } a, b;
+  a.t = v;
+#pragma unroll
+  for (int k = 0; k < W; ++k) b.w[k] = __builtin_amdgcn_update_dpp(0, a.w[k], CTRL, 0xf, 0xf, true);
+  return b.t;
+}
+
 // 16-byte pieces of a block of vectors: natural alignment of T on the global side (a group may
 // start on any column), 16 bytes on the LDS side.
 template <typename T, int EPL> struct VecU { T e[EPL]; };
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
     cps = (m + nsteps - 1) / nsteps;
     const int G = ng * cps;                   // staging groups per step
     const int64_t row = b * kWellRows + tid;
+    const bool whole_block = (b + 1) * kWellRows <= n_rows;     // workgroup-uniform: no row past the end
     // the row's entries: registers for the whole block of vectors (slots past the block's width
     // read the next block's entries -- the arrays are padded -- and are zeroed)
     // Positions: one register per entry holding the byte offset, or (PACK: 32 slots of an 8-byte
@@ -390,10 +402,45 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
         *reinterpret_cast<VecA<T, EPL> *>(ldsb + (lane8 * EPL + (boff + (unsigned)sbase[i]))) = val;
       }
     };
+    auto row_product = [&](unsigned bo) -> T {          // (A y)[row] for the vector staged at byte offset bo
+      asm volatile("" : "+s"(bo));
+      T acc = zero_of(T{});
+#pragma unroll
+      for (int t = 0; t < WMAX; ++t) fma_acc(acc, v[t], *reinterpret_cast<const T *>(ldsb + (entry_offset(t) + bo)));
+      return acc;
+    };
     auto compute = [&](int s) {
       unsigned boff = (unsigned)(s & 1) * (unsigned)(BUF * sizeof(T));
       int j = s * cps;
       const int jend = (j + cps < m) ? j + cps : m;
+      if constexpr (CHEB && sizeof(T) <= 8) {
+        // Two vectors at a time with the two results of a lane pair exchanged (DPP), so that a lane
+        // holds rows rb, rb + 1 of ONE vector: y, p, b are then read and p written as 2-element
+        // pieces (8 bytes for float, 16 for double) -- half the vector-memory instructions of the
+        // element-wise epilogue, which is what bounds the fused step at small block sizes.
+        if (whole_block) {
+          const int q = lane & 1;
+          const int64_t rb = row - q;
+          struct alignas(sizeof(T)) V2 { T e[2]; };
+          for (; j + 1 < jend; j += 2) {
+            const T a0 = row_product(boff), a1 = row_product(boff + (unsigned)F * (unsigned)sizeof(T));
+            boff += 2u * (unsigned)F * (unsigned)sizeof(T);
+            const T got = dpp_quad<T, 0xB1>(q ? a0 : a1);           // the neighbour's result for MY vector
+            const T t0 = q ? got : a0, t1 = q ? a1 : got;           // (A y) at rows rb, rb + 1 of vector j + q
+            const int64_t jq = j + q;
+            V2 *pp = reinterpret_cast<V2 *>(Y + rb + jq * ldy);
+            const V2 pv = *pp;
+            const V2 bv = *reinterpret_cast<const V2 *>(cheb.B + rb + jq * cheb.ldb);
+            const V2 yv = *reinterpret_cast<const V2 *>(X + rb + jq * ldx);
+            V2 out;
+            out.e[0] = add_of(add_of(scale_of(cheb.cy, yv.e[0]), scale_of(cheb.cp, pv.e[0])),
+                              scale_of(cheb.cb, sub_of(bv.e[0], t0)));
+            out.e[1] = add_of(add_of(scale_of(cheb.cy, yv.e[1]), scale_of(cheb.cp, pv.e[1])),
+                              scale_of(cheb.cb, sub_of(bv.e[1], t1)));
+            *pp = out;
+          }
+        }
+      }
       for (; j < jend; ++j) {
         asm volatile("" : "+s"(boff));
         T acc = zero_of(T{});
