@@ -53,7 +53,9 @@ struct GramArgs {
 // (three resident workgroups per CU measured faster in sustained back-to-back use than the four that
 // __launch_bounds__(256, 4) gives: 5.97 vs 5.53 TB/s)
 // MODE 0: general (unaligned layouts, several panels of a self-Gram): loads predicated per piece,
-//         one chunk in flight.
+//         one chunk in flight.  MODE 3 / 4: the same loop on row chunks twice / four times as long
+//         (1 / 2 KiB per column piece instead of 512 bytes: longer DRAM bursts, +2.5 % on the
+//         two-operand fp64 Gram) where the LDS tile and the loads of a chunk still fit.
 // MODE 1 / 2: aligned two-operand Gram / aligned single-panel self-Gram: the panel shape is known
 //         at compile time, so the loads of a chunk are straight-line code and the loop keeps TWO
 //         chunks in flight in two register sets (the compiler emits counted vmcnt waits only for
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
   using acc_t = typename M::acc_t;
   constexpr bool CPLX = DType<DT>::cplx;
   constexpr int NC = CPLX ? 2 : 1;               // reals per element
-  constexpr int ROWS = 512 / (int)sizeof(R);     // rows per chunk (64 f64 / 128 f32)
+  constexpr int RM = MODE == 3 ? 2 : (MODE == 4 ? 4 : 1);
+  constexpr int ROWS = RM * 512 / (int)sizeof(R);   // rows per chunk: 512-byte column pieces, 1 KiB (MODE 3), 2 KiB (MODE 4)
   constexpr int RPU = 16 / (int)sizeof(R);       // reals per 16-byte unit
   constexpr int UPC = ROWS * NC / RPU;           // units per T-column per chunk
   constexpr int VY = PI * 16, VX = PJ * 16;      // real (virtual) columns per panel
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
     }
   };
 
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || MODE >= 3) {
     int64_t chunk = blockIdx.x;
     if (chunk < a.nchunks) load_chunk(chunk);
     for (; chunk < a.nchunks; chunk += gridDim.x) {
@@ -396,7 +399,6 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
                      void *d_out) {
   using R = typename DType<DT>::R;
   constexpr int NC = DType<DT>::cplx ? 2 : 1;
-  constexpr int ROWS = 512 / (int)sizeof(R);
   Context &c = ctx();
   const int vx = (int)mx * NC, vy = (int)my * NC;
   const int PI = pick_tiles(vy), PJ = pick_tiles(vx);
@@ -404,20 +406,33 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   GramArgs a;
   a.X = X; a.Y = Y; a.ldx = ldx; a.ldy = ldy; a.n = n; a.mx = (int)mx; a.my = (int)my;
   a.same = (X == Y && ldx == ldy && mx == my) ? 1 : 0;
-  a.npj = npj; a.nchunks = (n + ROWS - 1) / ROWS; a.partials = c.work;
+  a.npj = npj; a.partials = c.work;
   const int64_t es = dtype_size(DT);
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
-  // kernel variant: see gram_kernel (RLH_GRAM_PIPE=0 forces the general loop: tunable)
-  // measured at n = 10^7, m = 32 fp64: the two-chunk pipeline gains 5 % on the self-Gram
-  // (0.50 -> 0.475 ms) and nothing on the two-operand Gram (0.885 vs 0.868 ms in sustained use), so
-  // the latter keeps the general loop unless RLH_GRAM_PIPE=2
+  // Kernel variant (see gram_kernel).  Measured at n = 10^7, m = 32 fp64: the two-chunk pipeline
+  // gains 5 % on the self-Gram (0.50 -> 0.475 ms) and nothing on the two-operand Gram (0.885 vs
+  // 0.868 ms in sustained use: RLH_GRAM_PIPE=2 selects it); 1 KiB column pieces gain 2.5 % on the
+  // two-operand Gram (0.889 -> 0.868 ms) and 2 KiB pieces 6-9 % at m = 16 (0.46 -> 0.427 ms).
+  // RLH_GRAM_PIPE=0: general loop only; RLH_GRAM_ROWS=1|2|4
+  // caps the piece length (tunables).
   static const int pipe = getenv("RLH_GRAM_PIPE") ? atoi(getenv("RLH_GRAM_PIPE")) : 1;
-  const int mode = (!aligned || pipe == 0) ? 0
-                   : (!a.same ? (pipe >= 2 ? 1 : 0) : ((npi == 1 && npj == 1 && PI == PJ) ? 2 : 0));
+  static const int rows_cap = getenv("RLH_GRAM_ROWS") ? atoi(getenv("RLH_GRAM_ROWS")) : 4;
+  int mode = 0;
+  if (aligned && pipe != 0) {
+    if (a.same && npi == 1 && npj == 1 && PI == PJ && PI <= 2) mode = 2;
+    else if (!a.same && pipe >= 2 && PI * PJ <= 4) mode = 1;
+    else if (PI <= 2 && PJ <= 2 && rows_cap >= 2) mode = (PI * PJ == 1 && rows_cap >= 4) ? 4 : 3;
+  }
+  const int ROWS = (mode == 3 ? 2 : (mode == 4 ? 4 : 1)) * 512 / (int)sizeof(R);
+  a.nchunks = (n + ROWS - 1) / ROWS;
 #define RLH_GRAM_CASE(pi, pj)                                                              \
   if (PI == pi && PJ == pj) {                                                              \
     if constexpr (pi * pj <= 4)       /* two register sets of a larger panel do not fit */ \
       if (mode == 1) return gram_launch<DT, pi, pj, true, 1>(a, npi, npj, my, mx, d_out);  \
+    if constexpr (pi <= 2 && pj <= 2) /* nor does the LDS tile of a longer chunk */        \
+      if (mode == 3) return gram_launch<DT, pi, pj, true, 3>(a, npi, npj, my, mx, d_out);  \
+    if constexpr (pi * pj == 1)                                                            \
+      if (mode == 4) return gram_launch<DT, pi, pj, true, 4>(a, npi, npj, my, mx, d_out);  \
     if constexpr (pi == pj && pi <= 2)                                                     \
       if (mode == 2) return gram_launch<DT, pi, pj, true, 2>(a, npi, npj, my, mx, d_out);  \
     return aligned ? gram_launch<DT, pi, pj, true, 0>(a, npi, npj, my, mx, d_out)          \
