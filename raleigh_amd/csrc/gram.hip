@@ -419,7 +419,7 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   static const int rows_cap = getenv("RLH_GRAM_ROWS") ? atoi(getenv("RLH_GRAM_ROWS")) : 4;
   int mode = 0;
   if (aligned && pipe != 0) {
-    if (a.same && npi == 1 && npj == 1 && PI == PJ && PI <= 2) mode = 2;
+    if (a.same && npi == 1 && npj == 1 && PI == PJ && PI <= 2) mode = 2;   // (longer chunks instead: 0.48 -> 0.535 ms)
     else if (!a.same && pipe >= 2 && PI * PJ <= 4) mode = 1;
     else if (PI <= 2 && PJ <= 2 && rows_cap >= 2) mode = (PI * PJ == 1 && rows_cap >= 4) ? 4 : 3;
   }

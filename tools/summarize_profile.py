@@ -11,7 +11,9 @@ import sys
 
 O = sys.argv[1]
 out = {}
-f = glob.glob(O + '/stats/*/*kernel_stats.csv')
+import os.path
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)     # a reused tag keeps older runs around
+f = [newest(O + '/stats/*/*kernel_stats.csv')]
 print('== rocprofv3 --kernel-trace --stats (bench.py --steps 5 --warmup 2)')
 for r in csv.DictReader(open(f[0])):
     name = r['Name'].split('(')[0].replace('void rlh::', '')
@@ -19,13 +21,13 @@ for r in csv.DictReader(open(f[0])):
         name[:58], r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6, r['Percentage']))
     out.setdefault('kernels', {})[name] = {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3}
 # per-dispatch durations of the two-operand Gram: those reading 2 blocks (grid identical; split by duration rank)
-trace = glob.glob(O + '/stats/*/*kernel_trace.csv')[0]
+trace = newest(O + '/stats/*/*kernel_trace.csv')
 durs = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     durs[r['Kernel_Name'].split('(')[0]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 acc = {}
 for tag in ('fetch', 'write'):
-    f = glob.glob(O + '/%s/*/*counter_collection.csv' % tag)[0]
+    f = newest(O + '/%s/*/*counter_collection.csv' % tag)
     a = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         a[r['Kernel_Name'].split('(')[0].replace('void rlh::', '')].append(float(r['Counter_Value']))
@@ -40,15 +42,17 @@ for k in sorted(acc['fetch']):
                                            'write_avg': sum(wr) / len(wr)}
 g = [k for k in acc['fetch'] if k.startswith('gram_kernel')]
 if g:
-    # the two-operand launches are the ones with the larger read volume
-    rd = sorted(2 * v * 1024 for v in acc['fetch'][g[0]])
+    # the two-operand launches: the Gram kernel variant with the larger read volume per launch
+    # (the self-Gram runs under another template instance or, in older builds, the same one)
+    gk = max(g, key=lambda k: max(acc['fetch'][k]))
+    rd = sorted(2 * v * 1024 for v in acc['fetch'][gk])
     two = [v for v in rd if v > 0.75 * rd[-1]]
-    wr = acc['write'][g[0]]
-    out['gram_two_operand'] = {'hbm_bytes_per_launch': int(sum(two) / len(two) + sum(wr) / len(wr) * 1024),
+    wr = acc['write'][gk]
+    out['gram_two_operand'] = {'kernel': gk, 'hbm_bytes_per_launch': int(sum(two) / len(two) + sum(wr) / len(wr) * 1024),
                                'launches': len(two)}
-    d = sorted(durs.get('void rlh::gram_kernel<1, 2, 2, true>', []))
+    d = sorted(durs.get('void rlh::' + gk, []))
     if d:
         twod = [v for v in d if v > 0.75 * d[-1]]
         out['gram_two_operand']['avg_us_rocprof'] = sum(twod) / len(twod)
-        print('two-operand Gram launches: avg %.1f us over %d dispatches (kernel trace)' % (sum(twod) / len(twod), len(twod)))
+        print('two-operand Gram launches (%s): avg %.1f us over %d dispatches (kernel trace)' % (gk, sum(twod) / len(twod), len(twod)))
 json.dump(out, open(O + '/summary.json', 'w'), indent=1)
