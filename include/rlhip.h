@@ -112,6 +112,15 @@ int rlh_block_update2(int dtype, int64_t n, int64_t k1, const void *X1, int64_t 
                       const void *X2, int64_t ldx2, const void *q2, int64_t q2_rs,
                       int64_t q2_cs, int64_t m, void *Out, int64_t ldo,
                       const double *alpha, int beta);
+/* Two result blocks from ONE pass over the two sources (the Rayleigh-Ritz update forms the new
+ * X and the new search directions Z from the same X, Y -- solver.py:1609-1656 issues a
+ * multiply + add pair for each):  [OutA | OutB] = X1 * q1 + X2 * q2,  q1: k1 x (ma + mb),
+ * q2: k2 x (ma + mb) host matrices (element strides as above), the first ma result columns go
+ * to OutA, the other mb to OutB. */
+int rlh_block_update2x2(int dtype, int64_t n, int64_t k1, const void *X1, int64_t ldx1,
+                        const void *q1, int64_t q1_rs, int64_t q1_cs, int64_t k2, const void *X2,
+                        int64_t ldx2, const void *q2, int64_t q2_rs, int64_t q2_cs, int64_t ma,
+                        void *OutA, int64_t ldoa, int64_t mb, void *OutB, int64_t ldob);
 int rlh_lincomb_cols(int dtype, int64_t n, int64_t m, const void *a, const void *A,
                      int64_t lda, const void *b, const void *B, int64_t ldb, void *Out,
                      int64_t ldo);

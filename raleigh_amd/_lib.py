@@ -47,6 +47,8 @@ SIGNATURES = {
     'rlh_block_update': [_int, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _int],
     'rlh_block_update2': [_int, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64,
                           _p, _int],
+    'rlh_block_update2x2': [_int, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64,
+                            _i64, _p, _i64],
     'rlh_lincomb_cols': [_int, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _p, _i64],
     'rlh_axpy': [_int, _i64, _i64, _p, _p, _i64, _p, _i64],
     'rlh_axpy_cols': [_int, _i64, _i64, _p, _p, _i64, _p, _i64],

@@ -311,6 +311,21 @@ class Vectors:
             q2.strides[0] // q2.itemsize, q2.strides[1] // q2.itemsize,
             m, output._ptr(), output._ld, _lib.host_ptr(a), 0))
 
+    def combine2(self, q_a, q_b, other, q_other_a, q_other_b, out_a, out_b):
+        """out_a = self * q_a + other * q_other_a and out_b = self * q_b + other * q_other_b from ONE
+        pass over self and other (the Rayleigh-Ritz update forms the new block and the new
+        directions from the same two blocks: solver.py:1609-1656)."""
+        dt = self._dtype
+        q = np.ascontiguousarray(np.concatenate((np.asarray(q_a, dtype=dt), np.asarray(q_b, dtype=dt)), axis=1))
+        q2 = np.ascontiguousarray(np.concatenate((np.asarray(q_other_a, dtype=dt), np.asarray(q_other_b, dtype=dt)), axis=1))
+        ma, mb = out_a.nvec(), out_b.nvec()
+        if q.shape != (self.nvec(), ma + mb) or q2.shape != (other.nvec(), ma + mb) or np.asarray(q_a).shape[1] != ma:
+            raise ValueError('coefficient matrices do not match the numbers of vectors')
+        _lib.check(_lib.lib().rlh_block_update2x2(
+            self._code, self._vdim, q.shape[0], self._ptr(), self._ld, _lib.host_ptr(q), ma + mb, 1,
+            q2.shape[0], other._ptr(), other._ld, _lib.host_ptr(q2), ma + mb, 1,
+            ma, out_a._ptr(), out_a._ld, mb, out_b._ptr(), out_b._ld))
+
     def lincomb(self, a, x, b, y):
         """self[i] = a[i] * x[i] + b[i] * y[i] (a, b scalars or per-vector arrays); self may be x or y.
         One pass instead of copy + add (solver.py:942-952)."""

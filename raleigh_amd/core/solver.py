@@ -866,13 +866,19 @@ class Solver:
             results = {}
             names = ['AX', 'X'] if std else ['AX', 'BX', 'X']
             olds = {'AX': (AX, AY, AZ), 'BX': (BX, BY, BZ), 'X': (X, Y, Z)}
+            fused2 = fused and hasattr(X, 'combine2') and nx_act > 0 and nz > 0
             for name in names:
                 SX, SY, SZ = olds[name]
-                if nz > 0:
-                    SZ.select(m)
-                    combine(SX, SY, SZ, QZ)
-                W.select(m)
-                combine(SX, SY, W, QX)
+                if fused2:      # both results from one pass over SX and SY
+                    SZ.select(QZ.shape[1])
+                    W.select(QX.shape[1])
+                    SX.combine2(QX[:nx_act], QZ[:nx_act], SY, QX[nx_act:], QZ[nx_act:], W, SZ)
+                else:
+                    if nz > 0:
+                        SZ.select(m)
+                        combine(SX, SY, SZ, QZ)
+                    W.select(m)
+                    combine(SX, SY, W, QX)
                 results[name] = W
                 W = SX
             AX, X = results['AX'], results['X']

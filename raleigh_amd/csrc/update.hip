@@ -34,12 +34,17 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
                                                            const T *__restrict__ X2, int64_t ldx2, int k2, int kpad,
                                                            T *__restrict__ Out, int64_t ldo,
                                                            const T *__restrict__ Q, int ldq, int64_t n, int k,
-                                                           int m) {
+                                                           int m, T *__restrict__ Out2, int64_t ldo2, int msplit) {
   using V = RowVec<T, RV>;
   const int j0 = blockIdx.y * JT;
   const int jv = (m - j0) < JT ? (m - j0) : JT;      // valid output columns of this panel
   const T *__restrict__ Qp = Q + j0;
-  T *__restrict__ Op = Out + (int64_t)j0 * ldo;
+  // output column j of the panel: columns < msplit live in Out, the others in Out2 (two result
+  // blocks from one pass over the sources: rlh_block_update2x2)
+  auto out_col = [&](int j) -> T * {
+    const int gj = j0 + j;
+    return gj < msplit ? Out + (int64_t)gj * ldo : Out2 + (int64_t)(gj - msplit) * ldo2;
+  };
   const int64_t stride = (int64_t)gridDim.x * 256 * RV;
   for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV; row < n; row += stride) {
     const bool whole = row + RV <= n;                // the last lane group of an n not divisible by RV
@@ -50,12 +55,12 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
       for (int r = 0; r < RV; ++r) acc[r][j] = zero_of(T{});
       if (BETA && j < jv) {
         if (whole) {
-          const V o = *reinterpret_cast<const V *>(Op + row + (int64_t)j * ldo);
+          const V o = *reinterpret_cast<const V *>(out_col(j) + row);
 #pragma unroll
           for (int r = 0; r < RV; ++r) acc[r][j] = o.e[r];
         } else {
           for (int r = 0; r < RV; ++r)
-            if (row + r < n) acc[r][j] = Op[row + r + (int64_t)j * ldo];
+            if (row + r < n) acc[r][j] = out_col(j)[row + r];
         }
       }
     }
@@ -93,10 +98,10 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
           V o;
 #pragma unroll
           for (int r = 0; r < RV; ++r) o.e[r] = acc[r][j];
-          *reinterpret_cast<V *>(Op + row + (int64_t)j * ldo) = o;
+          *reinterpret_cast<V *>(out_col(j) + row) = o;
         } else {
           for (int r = 0; r < RV; ++r)
-            if (row + r < n) Op[row + r + (int64_t)j * ldo] = acc[r][j];
+            if (row + r < n) out_col(j)[row + r] = acc[r][j];
         }
       }
   }
@@ -116,7 +121,7 @@ template <> struct HostScalar<c64> {
 
 template <typename T, int JT, int RV>
 static int launch_update_rv(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
-                            int beta, const T *X2, int64_t ldx2, int k2, int kpad) {
+                            int beta, const T *X2, int64_t ldx2, int k2, int kpad, T *Out2, int64_t ldo2, int msplit) {
   Context &c = ctx();
   int64_t nbx = ((n + RV - 1) / RV + 255) / 256;
   const int64_t cap = (int64_t)c.num_cu * 8;
@@ -124,26 +129,29 @@ static int launch_update_rv(const T *X, int64_t ldx, T *Out, int64_t ldo, const 
   dim3 grid((unsigned)nbx, (unsigned)((m + JT - 1) / JT));
   if (beta)
     hipLaunchKernelGGL((block_update_kernel<T, JT, true, RV>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
-                       Out, ldo, Qd, ldq, n, k, m);
+                       Out, ldo, Qd, ldq, n, k, m, Out2, ldo2, msplit);
   else
     hipLaunchKernelGGL((block_update_kernel<T, JT, false, RV>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
-                       Out, ldo, Qd, ldq, n, k, m);
+                       Out, ldo, Qd, ldq, n, k, m, Out2, ldo2, msplit);
   RLH_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T, int JT>
 static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
-                         int beta, const T *X2 = nullptr, int64_t ldx2 = 0, int k2 = 0, int kpad = 0) {
+                         int beta, const T *X2 = nullptr, int64_t ldx2 = 0, int k2 = 0, int kpad = 0,
+                         T *Out2 = nullptr, int64_t ldo2 = 0, int msplit = -1) {
+  if (msplit < 0 || !Out2) { msplit = m; Out2 = Out; ldo2 = ldo; }
   // 16-byte row groups where RV * JT accumulators of T fit (<= 128 registers) and every block is
   // 16-byte aligned (RLH_UPDATE_RV=0: one row per lane, tunable)
   constexpr int RVMAX = 16 / (int)sizeof(T);
   if constexpr (RVMAX > 1 && RVMAX * JT * sizeof(T) <= 512) {
     static const int rv = env_flag("RLH_UPDATE_RV", 1);
-    if (rv && aligned16(X, ldx, sizeof(T)) && aligned16(Out, ldo, sizeof(T)) && (!X2 || k2 == 0 || aligned16(X2, ldx2, sizeof(T))))
-      return launch_update_rv<T, JT, RVMAX>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad);
+    if (rv && aligned16(X, ldx, sizeof(T)) && aligned16(Out, ldo, sizeof(T)) && aligned16(Out2, ldo2, sizeof(T)) &&
+        (!X2 || k2 == 0 || aligned16(X2, ldx2, sizeof(T))))
+      return launch_update_rv<T, JT, RVMAX>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad, Out2, ldo2, msplit);
   }
-  return launch_update_rv<T, JT, 1>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad);
+  return launch_update_rv<T, JT, 1>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad, Out2, ldo2, msplit);
 }
 
 template <int DT>
@@ -197,7 +205,7 @@ template <int DT>
 static int block_update2_impl(int64_t n, int64_t k1, const void *X1_, int64_t ldx1, const void *q1_, int64_t q1_rs,
                               int64_t q1_cs, int64_t k2, const void *X2_, int64_t ldx2, const void *q2_,
                               int64_t q2_rs, int64_t q2_cs, int64_t m, void *Out_, int64_t ldo, const double *alpha,
-                              int beta) {
+                              int beta, void *OutB_ = nullptr, int64_t ldob = 0, int64_t ma = -1) {
   using T = typename DType<DT>::T;
   constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
   const T *q1 = (const T *)q1_, *q2 = (const T *)q2_;
@@ -219,15 +227,16 @@ static int block_update2_impl(int64_t n, int64_t k1, const void *X1_, int64_t ld
   const T *X1 = (const T *)X1_, *X2 = (const T *)X2_;
   T *Out = (T *)Out_;
   int rc;
+  T *OutB = (T *)OutB_;
   if (JT == 8)
     rc = launch_update<T, 8>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m, beta, X2, ldx2, (int)k2,
-                             (int)kp1);
+                             (int)kp1, OutB, ldob, (int)ma);
   else if (JT == 16)
     rc = launch_update<T, 16>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m, beta, X2, ldx2,
-                              (int)k2, (int)kp1);
+                              (int)k2, (int)kp1, OutB, ldob, (int)ma);
   else
     rc = launch_update<T, (JTMAX == 32 ? 32 : 16)>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m,
-                                                   beta, X2, ldx2, (int)k2, (int)kp1);
+                                                   beta, X2, ldx2, (int)k2, (int)kp1, OutB, ldob, (int)ma);
   if (rc) return rc;
   return ring_release(slot);
 }
@@ -568,6 +577,28 @@ int rlh_block_update2(int dtype, int64_t n, int64_t k1, const void *X1, int64_t 
   int rc = 0;
   RLH_DISPATCH(dtype, block_update2_impl, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, m, Out,
                ldo, alpha, beta)
+  return rc;
+}
+
+int rlh_block_update2x2(int dtype, int64_t n, int64_t k1, const void *X1, int64_t ldx1, const void *q1, int64_t q1_rs,
+                        int64_t q1_cs, int64_t k2, const void *X2, int64_t ldx2, const void *q2, int64_t q2_rs,
+                        int64_t q2_cs, int64_t ma, void *OutA, int64_t ldoa, int64_t mb, void *OutB, int64_t ldob) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_block_update2x2: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && k1 >= 1 && k2 >= 1 && ma >= 1 && mb >= 1, "rlh_block_update2x2: bad size");
+  if (n == 0) return 0;
+  RLH_REQUIRE(OutA && OutB && X1 && X2 && q1 && q2, "rlh_block_update2x2: null pointer");
+  RLH_REQUIRE(ldoa >= n && ldob >= n && ldx1 >= n && ldx2 >= n, "rlh_block_update2x2: leading dimension smaller than n");
+  const int64_t es = dtype_size(dtype);
+  const int64_t ba = ((ma - 1) * ldoa + n) * es, bb = ((mb - 1) * ldob + n) * es;
+  RLH_REQUIRE(!overlaps(X1, ((k1 - 1) * ldx1 + n) * es, OutA, ba) && !overlaps(X2, ((k2 - 1) * ldx2 + n) * es, OutA, ba) &&
+                  !overlaps(X1, ((k1 - 1) * ldx1 + n) * es, OutB, bb) && !overlaps(X2, ((k2 - 1) * ldx2 + n) * es, OutB, bb) &&
+                  !overlaps(OutA, ba, OutB, bb),
+              "rlh_block_update2x2: an output window overlaps an input window or the other output");
+  const double one[2] = {1.0, 0.0};
+  int rc = 0;
+  RLH_DISPATCH(dtype, block_update2_impl, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, ma + mb,
+               OutA, ldoa, one, 0, OutB, ldob, ma)
   return rc;
 }
 

@@ -194,6 +194,23 @@ class FakeLib:
         out[:, :] = (out + upd if beta else upd).astype(dt)
         return 0
 
+    def rlh_block_update2x2(self, code, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, ma, OutA, ldoa,
+                            mb, OutB, ldob):
+        self._count('block_update2x2')
+        if n == 0:
+            return 0
+        dt = np.dtype(_DT[code])
+        m = ma + mb
+
+        def qmat(q, k, rs, cs):
+            qf = _flat(q, dt, (k - 1) * rs + (m - 1) * cs + 1)
+            return np.lib.stride_tricks.as_strided(qf, shape=(k, m), strides=(rs * dt.itemsize, cs * dt.itemsize))
+        upd = qmat(q1, k1, q1_rs, q1_cs).T @ _block(X1, code, n, k1, ldx1) \
+            + qmat(q2, k2, q2_rs, q2_cs).T @ _block(X2, code, n, k2, ldx2)
+        _block(OutA, code, n, ma, ldoa)[:, :] = upd[:ma].astype(dt)
+        _block(OutB, code, n, mb, ldob)[:, :] = upd[ma:].astype(dt)
+        return 0
+
     def rlh_lincomb_cols(self, code, n, m, a, A, lda, b, B, ldb, Out, ldo):
         self._count('lincomb_cols')
         if n == 0 or m == 0:

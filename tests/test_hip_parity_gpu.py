@@ -569,3 +569,24 @@ def test_spmm_interior_boundary_parts(spmm_format, key):
     op.cheb_step_ptr(m, X, P, B, 1.2, -0.2, 0.4, Hbad.data_ptr(), Hbad.ld(), part=1)
     op.cheb_step_ptr(m, X, P, B, 1.2, -0.2, 0.4, Hgood.data_ptr(), Hgood.ld(), part=2)
     assert cases.rel(P.data(), 1.2 * x[:, r0:r1] - 0.2 * p0 + 0.4 * (b0 - ref)) < tol
+
+
+@pytest.mark.parametrize('key', KEYS)
+@pytest.mark.parametrize('shape', [(7, 5, 9, 4), (16, 16, 16, 16), (3, 20, 10, 27)])
+def test_combine2_two_outputs_one_pass(key, shape):
+    """rlh_block_update2x2 / Vectors.combine2: [A | B] = X qx + Y qy in one pass, against the oracle
+    (odd row count: the 16-byte row groups end in a partial one)."""
+    from raleigh_amd.algebra.hip import Vectors
+    k1, k2, ma, mb = shape
+    n = 20011
+    rng = np.random.default_rng(k1 + ma)
+    x, y = rnd((k1, n), key, rng), rnd((k2, n), key, rng)
+    qxa, qxb = rnd((k1, ma), key, rng), rnd((k1, mb), key, rng)
+    qya, qyb = rnd((k2, ma), key, rng), rnd((k2, mb), key, rng)
+    X, Y = Vectors(x), Vectors(y)
+    A, B = Vectors(n, ma, data_type=DT[key]), Vectors(n, mb, data_type=DT[key])
+    X.combine2(qxa, qxb, Y, qya, qyb, A, B)
+    tol = 2e-5 if key in 'sc' else 1e-13
+    assert cases.rel(A.data(), ops.multiply(x, qxa) + ops.multiply(y, qya)) < tol
+    assert cases.rel(B.data(), ops.multiply(x, qxb) + ops.multiply(y, qyb)) < tol
+    assert np.array_equal(X.data(), x) and np.array_equal(Y.data(), y)

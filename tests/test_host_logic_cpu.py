@@ -88,3 +88,17 @@ def test_fill_random_device_path(fake, monkeypatch):
     c = Vectors(1000, 3, data_type=np.complex64)
     c.fill_random()
     assert np.all(c.data().imag == 0) and c.data().real.std() > 0.5
+
+
+def test_combine2_host_logic(fake):
+    """Vectors.combine2 stacks the coefficient matrices and makes ONE library call."""
+    from raleigh_amd.algebra.hip import Vectors
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal((4, 300)), rng.standard_normal((3, 300))
+    qxa, qxb, qya, qyb = (rng.standard_normal(s) for s in ((4, 2), (4, 5), (3, 2), (3, 5)))
+    A, B = Vectors(300, 2), Vectors(300, 5)
+    Vectors(x).combine2(qxa, qxb, Vectors(y), qya, qyb, A, B)
+    assert fake.calls.get('block_update2x2', 0) == 1
+    assert np.allclose(A.data(), qxa.T @ x + qya.T @ y) and np.allclose(B.data(), qxb.T @ x + qyb.T @ y)
+    with pytest.raises(ValueError):
+        Vectors(x).combine2(qxa, qxb, Vectors(y), qya, qyb, B, A)
