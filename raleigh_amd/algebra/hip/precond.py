@@ -69,7 +69,7 @@ class ChebyshevPreconditioner:
             raise ValueError('low-precision evaluation needs an operator with cheb_step')
         ua.lincomb(1.0 / theta, b, 0.0, b)          # u_1 = x / theta
         if self._degree > 1:
-            ub.lincomb(0.0, b, 0.0, b)              # u_0 = 0 (a defined value: 0 * garbage could be NaN)
+            ub.zero()                               # u_0 = 0 (a defined value: 0 * garbage could be NaN)
         for _ in range(self._degree - 1):
             rho_new = 1.0 / (2.0 * sigma1 - rho)
             c, cb = rho_new * rho, 2.0 * rho_new / delta

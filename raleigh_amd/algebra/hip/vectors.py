@@ -366,12 +366,8 @@ class Vectors:
         m = self.nvec()
         if m < 1:
             return
-        L = _lib.lib()
-        if self._ld == self._vdim:
-            _lib.check(L.rlh_memset(self._ptr(), 0, m * self._ld * self._es))
-        else:
-            for i in range(m):
-                _lib.check(L.rlh_memset(self._ptr(self._sel[0] + i), 0, self._vdim * self._es))
+        # one fill over the window; the padding rows between the vectors belong to this block
+        _lib.check(_lib.lib().rlh_memset(self._ptr(), 0, ((m - 1) * self._ld + self._vdim) * self._es))
 
     def fill(self, data):
         if not isinstance(data, np.ndarray):        # fill(value), as dense_ndarray.py:98-100
