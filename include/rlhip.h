@@ -92,6 +92,10 @@ int rlh_dots(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx,
  * d_out[r] = sum_i conj(Y[r,i]) * X[r,i], r < n; device output of n elements. */
 int rlh_dots_transp(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx,
                     const void *Y, int64_t ldy, void *d_out);
+/* Largest modulus of the real / imaginary parts of the entries of a block (AMatrix.scale():
+ * the reference scans the host array, raleigh/algebra/dense_matrix.py:44-49); *h_out is a host
+ * double; the call synchronises. */
+int rlh_absmax(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, double *h_out);
 
 /* ---- K3/K4: block update (dense_numpy.py:84-105; dense_cublas.py:271-342)
  * Out[:,j] = beta*Out[:,j] + alpha * sum_{i<k} q[i,j] * X[:,i], j < m.

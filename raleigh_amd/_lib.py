@@ -43,6 +43,7 @@ SIGNATURES = {
     'rlh_copy2d': [_p, _i64, _p, _i64, _i64, _i64, _int],
     'rlh_gram': [_int, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _p],
     'rlh_dots': [_int, _i64, _i64, _p, _i64, _p, _i64, _p, _p],
+    'rlh_absmax': [_int, _i64, _i64, _p, _i64, ctypes.POINTER(ctypes.c_double)],
     'rlh_dots_transp': [_int, _i64, _i64, _p, _i64, _p, _i64, _p],
     'rlh_block_update': [_int, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _int],
     'rlh_block_update2': [_int, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64,

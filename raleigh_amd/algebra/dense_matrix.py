@@ -33,7 +33,7 @@ class AMatrix:
         self._arch = arch
         self._matrix = Matrix(a)                 # the upload is the copy: copy_data is moot
         self._rows = None
-        self._magnitude = float(max(abs(np.amin(a)), abs(np.amax(a)))) if a.size else 0.0
+        self._magnitude = None                   # found on the device when first asked for
 
     # -- what the interfaces ask for
     def as_operator(self):
@@ -71,4 +71,6 @@ class AMatrix:
 
     def scale(self):
         """Largest entry in modulus of the host data (used to scale error estimates)."""
+        if self._magnitude is None:
+            self._magnitude = self._matrix.absmax()
         return self._magnitude

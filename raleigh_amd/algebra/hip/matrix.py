@@ -80,6 +80,15 @@ class Matrix:
         v = Vectors(self, shallow=True)
         return v.dots(v)
 
+    def absmax(self):
+        """Largest modulus of the (real / imaginary parts of the) entries, computed on the device."""
+        import ctypes
+        rows = self._shape[0] if self._order == 'C_CONTIGUOUS' else self._shape[1]
+        cols = self._shape[1] if self._order == 'C_CONTIGUOUS' else self._shape[0]
+        out = ctypes.c_double()
+        _lib.check(_lib.lib().rlh_absmax(self._code, cols, rows, self.data_ptr(), self._lda, ctypes.byref(out)))
+        return float(out.value)
+
     def new_vectors(self, dim=None, nv=0):
         if dim is None:
             dim = self.shape()[1]

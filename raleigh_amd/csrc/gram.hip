@@ -551,6 +551,59 @@ static int dots_impl(int64_t n, int64_t m, const void *X, int64_t ldx, const voi
   return 0;
 }
 
+// ---------------------------------------------------------------- largest modulus of the entries
+// max_ij max(|re x_ij|, |im x_ij|) of a block viewed as reals (AMatrix.scale(): the reference scans
+// the host array with numpy amin/amax, raleigh/algebra/dense_matrix.py:44-49 -- 0.1 s for 20000^2).
+template <typename R>
+__global__ __launch_bounds__(256) void absmax_kernel(const R *X, int64_t ldx_r, int64_t n_r, double *partials, int nbx) {
+  const R *x = X + (int64_t)blockIdx.y * ldx_r;
+  double mx = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_r; r += stride) {
+    const double v = fabs((double)x[r]);
+    mx = v > mx ? v : mx;                      // (a NaN entry is skipped, as numpy's fmax would)
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * nbx + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void absmax_finalize(const double *partials, int64_t count, double *out) {
+  double mx = 0.0;
+  for (int64_t i = threadIdx.x; i < count; i += 256) mx = partials[i] > mx ? partials[i] : mx;
+  __shared__ double red[256];
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+template <int DT>
+static int absmax_impl(int64_t n, int64_t m, const void *X, int64_t ldx, void *d_out) {
+  using R = typename DType<DT>::R;
+  constexpr int NC = DType<DT>::cplx ? 2 : 1;
+  Context &c = ctx();
+  int64_t nbx = (n * NC + 256 * 8 - 1) / (256 * 8);
+  const int64_t cap = ((int64_t)c.num_cu * 8 + m - 1) / m;
+  if (nbx > cap) nbx = cap;
+  if (nbx < 1) nbx = 1;
+  RLH_REQUIRE((size_t)nbx * m * sizeof(double) <= kWorkspaceBytes, "rlh_absmax: too many columns");
+  hipLaunchKernelGGL((absmax_kernel<R>), dim3((unsigned)nbx, (unsigned)m), dim3(256), 0, c.stream, (const R *)X,
+                     ldx * NC, n * NC, (double *)c.work, (int)nbx);
+  RLH_HIP(hipGetLastError());
+  hipLaunchKernelGGL(absmax_finalize, dim3(1), dim3(256), 0, c.stream, (const double *)c.work, nbx * m, (double *)d_out);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- transposed dots (K2t)
 template <typename T>
 __global__ __launch_bounds__(256) void dots_transp_kernel(const T *X, int64_t ldx, const T *Y, int64_t ldy,
@@ -641,6 +694,21 @@ int rlh_dots(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, const 
   if (rc) return rc;
   if (h_out) return fetch_result(h_out, d_out, bytes);
   return 0;
+}
+
+int rlh_absmax(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, double *h_out) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_absmax: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0 && m <= 65535, "rlh_absmax: bad size");
+  RLH_REQUIRE(h_out != nullptr, "rlh_absmax: null output");
+  if (n == 0 || m == 0) { *h_out = 0.0; return 0; }
+  RLH_REQUIRE(X && ldx >= n, "rlh_absmax: bad block");
+  if (int rc = ensure_result(sizeof(double))) return rc;
+  void *d_out = ctx().result_hd;      // written by the finalize kernel into mapped host memory
+  int rc = 0;
+  RLH_DISPATCH(dtype, absmax_impl, n, m, X, ldx, d_out)
+  if (rc) return rc;
+  return fetch_result(h_out, d_out, sizeof(double));
 }
 
 int rlh_dots_transp(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx, const void *Y, int64_t ldy,

@@ -271,6 +271,12 @@ class FakeLib:
             _block(X, code, n, m, ldx)[:, :] = ops.uniform_block(int(seed), n, m, _DT[code], row0, col0)
         return 0
 
+    def rlh_absmax(self, code, n, m, X, ldx, h_out):
+        x = _block(X, code, n, m, ldx)
+        val = 0.0 if x.size == 0 else max(float(np.max(np.abs(x.real))), float(np.max(np.abs(x.imag))))
+        ctypes.cast(h_out, ctypes.POINTER(ctypes.c_double))[0] = val
+        return 0
+
     def rlh_conj(self, code, n, m, X, ldx):
         if code in (2, 3):
             x = _block(X, code, n, m, ldx)

@@ -590,3 +590,16 @@ def test_combine2_two_outputs_one_pass(key, shape):
     assert cases.rel(A.data(), ops.multiply(x, qxa) + ops.multiply(y, qya)) < tol
     assert cases.rel(B.data(), ops.multiply(x, qxb) + ops.multiply(y, qyb)) < tol
     assert np.array_equal(X.data(), x) and np.array_equal(Y.data(), y)
+
+
+@pytest.mark.parametrize('key', KEYS)
+def test_absmax(key):
+    """rlh_absmax / Matrix.absmax: the exact maximum (no rounding involved), C- and F-ordered data,
+    a leading dimension larger than the row."""
+    from raleigh_amd.algebra.hip import Matrix
+    rng = np.random.default_rng(31)
+    a = rnd((301, 1237), key, rng)
+    a[17, 1001] *= 40
+    want = max(np.max(np.abs(a.real)), np.max(np.abs(a.imag)))
+    assert Matrix(a).absmax() == float(want)
+    assert Matrix(np.asfortranarray(a)).absmax() == float(want)
