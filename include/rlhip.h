@@ -206,6 +206,18 @@ int rlh_spmm_part(rlh_csr_t h, int part, int64_t m, const void *X, int64_t ldx, 
 int rlh_spmm_cheb_part(rlh_csr_t h, int part, int64_t m, const void *Y, int64_t ldy, int64_t n_own,
                        const void *H, int64_t ldh, void *P, int64_t ldp, const void *B, int64_t ldb,
                        double cy, double cp, double cb);
+/* bfloat16 storage for the device polynomial preconditioner (not in the reference).  A bf16 block
+ * is a column-major array of 16-bit words, leading dimension in elements (a multiple of 8), base
+ * 16-byte aligned.  pack: Y16 = bf16(scale * X) (round to nearest even) from a float32 / float64
+ * block; unpack: back to float32 / float64.  rlh_spmm_cheb_bf16 is rlh_spmm_cheb on three bf16
+ * blocks with float32 arithmetic against a square float32 operator in the windowed layout
+ * (single GPU; returns an error otherwise, the caller then stays in float32). */
+int rlh_bf16_pack(int src_dtype, int64_t n, int64_t m, const void *X, int64_t ldx, double scale,
+                  void *Y16, int64_t ldy);
+int rlh_bf16_unpack(int dst_dtype, int64_t n, int64_t m, const void *X16, int64_t ldx, void *Y,
+                    int64_t ldy);
+int rlh_spmm_cheb_bf16(rlh_csr_t h, int64_t m, const void *Y16, int64_t ldy, void *P16, int64_t ldp,
+                       const void *B16, int64_t ldb, double cy, double cp, double cb);
 /* Packs rows for the halo exchange: Out[i, j] = X[idx[i], j], i < nidx, j < m;
  * idx: DEVICE int64 (built once per operator). */
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m,

@@ -165,3 +165,20 @@ def uniform_block(seed, n, m, dtype, row0=0, col0=0):
         u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
         out = np.float32(2) * u - np.float32(1)
     return out.astype(dtype)
+
+
+def bf16_round(x):
+    """float32 values rounded to the nearest bfloat16 (ties to even), returned as float32 --
+    the storage rounding of rlh_bf16_pack / rlh_spmm_cheb_bf16 (not in the reference)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xFFFF0000)
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def bf16_bits(x):
+    """The 16-bit patterns of bf16_round(x)."""
+    return (bf16_round(x).view(np.uint32) >> np.uint32(16)).astype(np.uint16)
+
+
+def bf16_from_bits(h):
+    return (np.asarray(h, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)

@@ -22,7 +22,7 @@ def gershgorin_upper_bound(matrix):
 
 class ChebyshevPreconditioner:
 
-    def __init__(self, op, hi, ratio=50.0, degree=6, low_precision_op=None):
+    def __init__(self, op, hi, ratio=50.0, degree=6, low_precision_op=None, storage=None):
         """op: operator with apply(x, y); hi: upper bound of its spectrum; the polynomial
         approximates 1/x on [hi / ratio, hi]; degree: number of operator applications.
 
@@ -32,6 +32,14 @@ class ChebyshevPreconditioner:
         (nearly) symmetric positive definite approximation of A^-1, which single precision is."""
         if degree < 1:
             raise ValueError('degree must be at least 1')
+        if storage not in (None, 'bf16'):
+            raise ValueError("storage must be None or 'bf16'")
+        # storage='bf16' (with a float32 low_precision_op in the windowed device layout): the
+        # three work blocks are kept in bfloat16, arithmetic stays float32 -- half the bytes again
+        # per step; on lap3d 64^3 (degree 24) the iteration count goes from 27 to 28.  Ignored
+        # (float32 storage) where the operator cannot do it (sharded, sliced layout, complex).
+        self._bf16 = storage == 'bf16'
+        self._work16 = None
         self._op = op if low_precision_op is None else low_precision_op
         self._low = low_precision_op is not None
         self._lo, self._hi = float(hi) / float(ratio), float(hi)
@@ -44,6 +52,9 @@ class ChebyshevPreconditioner:
         u_{k+1} overwrites u_{k-1} (only its own row is needed), so two blocks ping-pong and a
         fused step reads u_k, u_{k-1}, x and writes u_{k+1} (`cheb_step`)."""
         m = x.nvec()
+        if self._bf16 and self._low and not x.is_complex() and getattr(self._op, 'supports_bf16', lambda: False)():
+            self._apply_bf16(x, y, m)
+            return
         nwork = 3 if self._low else 2
         if self._work is None or self._work[0].nvec() < m or self._work[0].dimension() != x.dimension():
             dt = None
@@ -84,3 +95,25 @@ class ChebyshevPreconditioner:
             rho = rho_new
         if self._low:
             ua.convert_to(y)
+
+    def _apply_bf16(self, x, y, m):
+        from .sparse import Bf16Block
+        n = x.dimension()
+        if self._work16 is None or self._work16[0].m < m or self._work16[0].n != n:
+            self._work16 = [Bf16Block(n, m) for _ in range(3)]
+        b, ua, ub = self._work16
+        theta, delta = 0.5 * (self._hi + self._lo), 0.5 * (self._hi - self._lo)
+        sigma1 = theta / delta
+        rho = 1.0 / sigma1
+        b.pack(x, 1.0)
+        ua.pack(x, 1.0 / theta)                     # u_1 = x / theta
+        if self._degree > 1:
+            ub.zero(m)                              # u_0 = 0
+        for _ in range(self._degree - 1):
+            rho_new = 1.0 / (2.0 * sigma1 - rho)
+            c, cb = rho_new * rho, 2.0 * rho_new / delta
+            self._op.cheb_step_bf16(m, ua, ub, b, 1.0 + c, -c, cb)
+            ua, ub = ub, ua
+            rho = rho_new
+        ua.unpack(y)
+        self._work16 = [b, ua, ub]

@@ -75,11 +75,40 @@ class CsrOperator:
         """part 0: all rows; 1: the rows that need no halo column; 2: the others (rlh_spmm_part)."""
         _lib.check(_lib.lib().rlh_spmm_part(self._h, part, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
 
+    def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
+        _lib.check(_lib.lib().rlh_spmm_cheb_bf16(self._h, m, y.ptr(), y.ld, p.ptr(), p.ld, b.ptr(), b.ld,
+                                                 float(cy), float(cp), float(cb)))
+
     def cheb_step_ptr(self, m, y, p, b, cy, cp, cb, halo_ptr=None, ldh=0, part=0):
         """p = cy y + cp p + cb (b - A y) in one pass (y, p, b: Vectors windows; p updated in place)."""
         _lib.check(_lib.lib().rlh_spmm_cheb_part(self._h, part, m, y.data_ptr(), y.ld(), self._n_own, halo_ptr, ldh,
                                                  p.data_ptr(), p.ld(), b.data_ptr(), b.ld(),
                                                  float(cy), float(cp), float(cb)))
+
+
+class Bf16Block:
+    """A block of vectors stored as bfloat16 (device memory, column-major, leading dimension a
+    multiple of 8): work storage of the polynomial preconditioner, not a Vectors type."""
+
+    def __init__(self, n, m):
+        from .memory import DeviceBuffer
+        self.n, self.m = int(n), int(m)
+        self.ld = -(-self.n // 64) * 64
+        self._buf = DeviceBuffer(max(self.m, 1) * self.ld * 2, zero=False)
+
+    def ptr(self):
+        return self._buf.ptr
+
+    def zero(self, m):
+        _lib.check(_lib.lib().rlh_memset(self._buf.ptr, 0, ((m - 1) * self.ld + self.n) * 2))
+
+    def pack(self, x, scale=1.0):
+        """self[:, :m] = bf16(scale * x) for a float32 / float64 Vectors window x."""
+        _lib.check(_lib.lib().rlh_bf16_pack(x._code, self.n, x.nvec(), x.data_ptr(), x.ld(), float(scale),
+                                            self._buf.ptr, self.ld))
+
+    def unpack(self, y):
+        _lib.check(_lib.lib().rlh_bf16_unpack(y._code, self.n, y.nvec(), self._buf.ptr, self.ld, y.data_ptr(), y.ld()))
 
 
 class SparseSymmetricMatrix:
@@ -117,6 +146,14 @@ class SparseSymmetricMatrix:
     def cheb_step(self, y, p, b, cy, cp, cb):
         """Fused step of the three-term Chebyshev semi-iteration: p = cy y + cp p + cb (b - A y)."""
         self.__op.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
+
+    def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
+        """The same step on bfloat16 blocks (Bf16Block), float32 arithmetic; float32 operators in
+        the windowed layout only (the library reports an error otherwise)."""
+        self.__op.cheb_step_bf16(m, y, p, b, cy, cp, cb)
+
+    def supports_bf16(self):
+        return self.__op.data_type() == np.float32 and self.__op.layout()[0] == 'well'
 
 
 class Operator:

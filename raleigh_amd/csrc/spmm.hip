@@ -353,7 +353,7 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
     // this thread's share of a step's staging: one load moves EPL elements per lane, i.e. EPL
     // consecutive 64-column groups per wave; slot i of the wave covers groups q .. q + EPL - 1,
     // q = EPL (wave + 16 i), of the step's G (vector cc = q / ng of the step, groups q % ng .. of
-    // the block: ng is a multiple of 4, so a slot never straddles two vectors)
+    // the block: ng is a multiple of 8, so a slot never straddles two vectors)
     constexpr int SLOTS = SMAX / EPL;
     constexpr int LPG = 64 / EPL;             // lanes per group
     int sbase[SLOTS];                         // byte offset of the slot's groups in an LDS buffer (wave-uniform)
@@ -514,6 +514,183 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
     __syncthreads();                          // the next block's first stage overwrites the buffers
   }
 }
+
+// ------------------------------------------------------------------ bfloat16 Chebyshev step
+// The fused three-term step with the three blocks y, p, b stored as bfloat16 (the preconditioner
+// only steers the search directions: on lap3d 64^3, degree 24, the iteration count goes from 27 to
+// 28 with bfloat16 storage) and all arithmetic in float32 against the float32 windowed operator.
+// Per element the step then moves 2-byte values: 4.5 x 2 bytes instead of 4.5 x 4.
+//  * staging: a 16-byte piece is 8 elements, one wave load covers 8 groups (1 KiB); the LDS image
+//    is bfloat16 (an entry's position times 2 is its byte offset), 8 vectors per step;
+//  * the row results of 8 vectors go through a wave-private LDS tile [vector][row] and come back
+//    as 8 consecutive rows of ONE vector per lane, so y, p, b are read and p is written as 16-byte
+//    pieces (one wave access = the wave's 64 rows x 8 vectors).
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {           // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+struct alignas(16) Bf8 { unsigned short e[8]; };
+struct alignas(8) Bf8U { unsigned short e[8]; };                           // staging piece: groups start on multiples of 4 columns
+
+constexpr int kBfCps = 8;                          // vectors per step (fewer when 8 staged images exceed a buffer)
+constexpr int kBfBufBytes = 56 * 1024;             // per staging buffer (2 of them + 32 KiB of wave tiles)
+
+template <int WMAX>
+__global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__restrict__ meta,
+                                                              const int32_t *__restrict__ gsrc,
+                                                              const uint16_t *__restrict__ idx,
+                                                              const float *__restrict__ vals, int64_t n_rows,
+                                                              const int32_t *__restrict__ sched, int64_t sched_len,
+                                                              const unsigned short *__restrict__ Yk, int64_t ldy,
+                                                              unsigned short *__restrict__ P, int64_t ldp,
+                                                              const unsigned short *__restrict__ B, int64_t ldb,
+                                                              int m, float cy, float cp, float cb) {
+  constexpr int SLOTS = 4;                         // ceil(56 KiB / 16 B / 1024 threads)
+  __shared__ __attribute__((aligned(16))) char ldsb[2 * kBfBufBytes + 16 * kBfCps * 64 * 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *tile = reinterpret_cast<float *>(ldsb + 2 * kBfBufBytes) + wave * (kBfCps * 64);   // [vector][row] of this wave
+  for (int64_t pos = blockIdx.x; pos < sched_len; pos += gridDim.x) {
+    const int64_t b = sched[pos];
+    if (b < 0) continue;
+    const WellMeta mt = meta[b];
+    const int width = mt.width_ng & 255;
+    const int ng = mt.width_ng >> 8;               // multiple of 8, <= 128
+    const int F2 = ng * 128;                       // bytes per staged vector
+    int cps = kBfBufBytes / F2;                    // >= 3
+    if (cps > kBfCps) cps = kBfCps;
+    if (cps > m) cps = m;
+    const int nsteps = (m + cps - 1) / cps;
+    const int G = ng * cps;                        // staging groups per step (G / 8 <= 56 pieces: 4 per wave)
+    const int64_t row0 = b * kWellRows + (int64_t)wave * 64;      // first row of this wave
+    const int64_t row = row0 + lane;
+    float v[WMAX];
+    unsigned ixb[WMAX];
+#pragma unroll
+    for (int t = 0; t < WMAX; ++t) {
+      const int64_t e = (mt.eoff + t) * kWellRows + tid;
+      const float val = __builtin_nontemporal_load(vals + e);
+      const unsigned pos_t = __builtin_nontemporal_load(idx + e);
+      v[t] = t < width ? val : 0.f;
+      ixb[t] = t < width ? pos_t * 2u : 0u;
+    }
+    // staging slots: 8 groups (one 16-byte piece per lane) each
+    int sbase[SLOTS], scc[SLOTS], scol[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      int q = (wave + 16 * i) * 8;
+      if (q > G - 8) q = G - 8;                    // surplus slots repeat the last groups
+      const int cc = q / ng, g = q - cc * ng;
+      scc[i] = __builtin_amdgcn_readfirstlane(cc);
+      sbase[i] = __builtin_amdgcn_readfirstlane(cc * F2 + g * 128);
+      scol[i] = gsrc[mt.goff + g + lane / 8] + (lane % 8) * 8;
+    }
+    Bf8U stA[SLOTS], stB[SLOTS];
+    auto stage_load = [&](int s, Bf8U (&st)[SLOTS]) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        int j = s * cps + scc[i];
+        if (j > m - 1) j = m - 1;
+        st[i] = *reinterpret_cast<const Bf8U *>(Yk + (int64_t)j * ldy + scol[i]);
+      }
+    };
+    auto stage_write = [&](int s, const Bf8U (&st)[SLOTS]) {
+      unsigned boff = (unsigned)(s & 1) * (unsigned)kBfBufBytes;
+      asm volatile("" : "+s"(boff));
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        Bf8 val;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val.e[k] = st[i].e[k];
+        *reinterpret_cast<Bf8 *>(ldsb + ((unsigned)lane * 16u + (boff + (unsigned)sbase[i]))) = val;
+      }
+    };
+    auto compute = [&](int s) {
+      unsigned boff = (unsigned)(s & 1) * (unsigned)kBfBufBytes;
+      const int j0 = s * cps;
+      // (A y)[row] for the step's vectors -> the wave's tile
+#pragma unroll 1
+      for (int c = 0; c < cps; ++c) {
+        unsigned bo = boff + (unsigned)c * (unsigned)F2;
+        asm volatile("" : "+s"(bo));
+        float acc = 0.f;
+        if (j0 + c < m) {
+#pragma unroll
+          for (int t = 0; t < WMAX; ++t)
+            acc = fmaf(v[t], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + (ixb[t] + bo))), acc);
+        }
+        tile[c * 64 + lane] = acc;
+      }
+      // lane L now takes vector j0 + L / 8, rows 8 (L % 8) .. + 7 of the wave's 64
+      const int c = lane >> 3, rg = lane & 7;
+      const int j = j0 + c;
+      const int64_t r8 = row0 + rg * 8;
+      float t8[8];
+      {
+        const float4 lo = *reinterpret_cast<const float4 *>(tile + c * 64 + rg * 8);
+        const float4 hi = *reinterpret_cast<const float4 *>(tile + c * 64 + rg * 8 + 4);
+        t8[0] = lo.x; t8[1] = lo.y; t8[2] = lo.z; t8[3] = lo.w;
+        t8[4] = hi.x; t8[5] = hi.y; t8[6] = hi.z; t8[7] = hi.w;
+      }
+      if (c < cps && j < m && r8 < n_rows) {
+        unsigned short *pp = P + (int64_t)j * ldp + r8;
+        const unsigned short *bp = B + (int64_t)j * ldb + r8, *yp = Yk + (int64_t)j * ldy + r8;
+        if (r8 + 8 <= n_rows) {
+          const Bf8 pv = *reinterpret_cast<const Bf8 *>(pp);       // (the host checked 16-byte alignment)
+          const Bf8 bv = *reinterpret_cast<const Bf8 *>(bp);
+          const Bf8 yv = *reinterpret_cast<const Bf8 *>(yp);
+          Bf8 out;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            out.e[k] = f32_to_bf16(cy * bf16_to_f32(yv.e[k]) + cp * bf16_to_f32(pv.e[k]) +
+                                   cb * (bf16_to_f32(bv.e[k]) - t8[k]));
+          *reinterpret_cast<Bf8 *>(pp) = out;
+        } else {                                   // the last rows of the matrix
+          for (int k = 0; k < 8 && r8 + k < n_rows; ++k)
+            pp[k] = f32_to_bf16(cy * bf16_to_f32(yp[k]) + cp * bf16_to_f32(pp[k]) + cb * (bf16_to_f32(bp[k]) - t8[k]));
+        }
+      }
+    };
+    stage_load(0, stA);
+    stage_load(1, stB);                            // (clamped to the last vector if there is no step 1)
+    stage_write(0, stA);
+    __syncthreads();
+    int s = 0;
+    for (; s + 3 < nsteps; s += 2) {
+      stage_load(s + 2, stA);
+      compute(s);
+      stage_write(s + 1, stB);
+      __syncthreads();
+      stage_load(s + 3, stB);
+      compute(s + 1);
+      stage_write(s + 2, stA);
+      __syncthreads();
+    }
+    const int left = nsteps - s;
+    if (left == 3) {
+      stage_load(s + 2, stA);
+      compute(s);
+      stage_write(s + 1, stB);
+      __syncthreads();
+      compute(s + 1);
+      stage_write(s + 2, stA);
+      __syncthreads();
+      compute(s + 2);
+    } else if (left == 2) {
+      compute(s);
+      stage_write(s + 1, stB);
+      __syncthreads();
+      compute(s + 1);
+    } else {
+      compute(s);
+    }
+    __syncthreads();
+  }
+}
+
 
 template <typename T, int WMAX, int EPL>
 static int launch_well_we(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
@@ -849,8 +1026,9 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
       ws.push_back(Win{0, 1, 0});
       off = 64;
     }
-    off = (off + 255) / 256 * 256;               // groups per block: a multiple of 4 (one 16-byte load
-                                                 // covers 2 or 4 groups); the extra ones repeat the last
+    off = (off + 511) / 512 * 512;               // groups per block: a multiple of 8 (one 16-byte load
+                                                 // covers 2, 4 or -- bfloat16 -- 8 groups); the extra ones
+                                                 // repeat the last
     ngroups[b] = off / 64;
   });
   int32_t wmax = 0, gmax = 0;
@@ -1084,6 +1262,34 @@ int rlh_spmm_cheb_part(rlh_csr_t h, int part, int64_t m, const void *Y, int64_t 
 int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_own, const void *H, int64_t ldh,
                   void *P, int64_t ldp, const void *B, int64_t ldb, double cy, double cp, double cb) {
   return rlh_spmm_cheb_part(h, 0, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
+}
+
+int rlh_spmm_cheb_bf16(rlh_csr_t h, int64_t m, const void *Y16, int64_t ldy, void *P16, int64_t ldp, const void *B16,
+                       int64_t ldb, double cy, double cp, double cb) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(h != nullptr, "rlh_spmm_cheb_bf16: null handle");
+  RLH_REQUIRE(m >= 0, "rlh_spmm_cheb_bf16: negative block size");
+  if (m == 0 || h->n_rows == 0) return 0;
+  RLH_REQUIRE(h->dtype == RLH_S && h->well_blocks > 0 && h->well_inbounds && h->n_rows == h->n_cols,
+              "rlh_spmm_cheb_bf16: needs a square float32 operator in the windowed layout with every staging "
+              "group inside the column range");
+  RLH_REQUIRE(Y16 && P16 && B16 && P16 != Y16 && P16 != B16, "rlh_spmm_cheb_bf16: bad block pointers");
+  RLH_REQUIRE(ldy >= h->n_cols && ldp >= h->n_rows && ldb >= h->n_rows && ldy % 8 == 0 && ldp % 8 == 0 && ldb % 8 == 0 &&
+                  ((uintptr_t)Y16 % 16) == 0 && ((uintptr_t)P16 % 16) == 0 && ((uintptr_t)B16 % 16) == 0,
+              "rlh_spmm_cheb_bf16: blocks must be 16-byte aligned with leading dimensions that are multiples of 8");
+  Context &c = ctx();
+  const unsigned short *Y = (const unsigned short *)Y16, *B = (const unsigned short *)B16;
+  unsigned short *P = (unsigned short *)P16;
+#define RLH_BF_LAUNCH(W)                                                                                          \
+  hipLaunchKernelGGL((well_cheb_bf16_kernel<W>), dim3((unsigned)h->well_grid), dim3(1024), 0, c.stream, h->well_meta, \
+                     h->well_gsrc, h->well_idx, (const float *)h->well_vals, h->n_rows, h->well_sched,            \
+                     h->well_sched_len, Y, ldy, P, ldp, B, ldb, (int)m, (float)cy, (float)cp, (float)cb)
+  if (h->well_wmax <= 8) RLH_BF_LAUNCH(8);
+  else if (h->well_wmax <= 16) RLH_BF_LAUNCH(16);
+  else RLH_BF_LAUNCH(32);
+#undef RLH_BF_LAUNCH
+  RLH_HIP(hipGetLastError());
+  return 0;
 }
 
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m, const void *X, int64_t ldx, void *Out,

@@ -402,6 +402,31 @@ __global__ __launch_bounds__(256) void fill_random_kernel(R *X, int64_t ldx_r, i
   }
 }
 
+// bfloat16 storage of a real block (device polynomial preconditioner): Y16 = bf16(scale * X),
+// round to nearest even, and back.
+template <typename TS>
+__global__ __launch_bounds__(256) void bf16_pack_kernel(const TS *__restrict__ X, int64_t ldx, float scale,
+                                                        unsigned short *__restrict__ Y, int64_t ldy, int64_t n) {
+  const TS *x = X + (int64_t)blockIdx.y * ldx;
+  unsigned short *y = Y + (int64_t)blockIdx.y * ldy;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
+    unsigned u = __float_as_uint(scale * (float)x[r]);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    y[r] = (unsigned short)(u >> 16);
+  }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void bf16_unpack_kernel(const unsigned short *__restrict__ X, int64_t ldx,
+                                                          TD *__restrict__ Y, int64_t ldy, int64_t n) {
+  const unsigned short *x = X + (int64_t)blockIdx.y * ldx;
+  TD *y = Y + (int64_t)blockIdx.y * ldy;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride)
+    y[r] = (TD)__uint_as_float((unsigned)x[r] << 16);
+}
+
 static inline unsigned row_blocks(int64_t items, int64_t m) {
   Context &c = ctx();
   int64_t nb = (items + 256 * 4 - 1) / (256 * 4);            // ~4 items per lane
@@ -713,6 +738,40 @@ int rlh_fill_random(int dtype, int64_t n, int64_t m, void *X, int64_t ldx, uint6
     case RLH_C: hipLaunchKernelGGL((fill_random_kernel<float, 2>), grid, dim3(256), 0, st, (float *)X, 2 * ldx, n, seed, row0, col0); break;
     case RLH_Z: hipLaunchKernelGGL((fill_random_kernel<double, 2>), grid, dim3(256), 0, st, (double *)X, 2 * ldx, n, seed, row0, col0); break;
   }
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+int rlh_bf16_pack(int src_dtype, int64_t n, int64_t m, const void *X, int64_t ldx, double scale, void *Y16, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(src_dtype == RLH_S || src_dtype == RLH_D, "rlh_bf16_pack: real blocks only");
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_bf16_pack: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(X && Y16 && ldx >= n && ldy >= n, "rlh_bf16_pack: bad arguments");
+  dim3 grid(row_blocks(n, m), (unsigned)m);
+  if (src_dtype == RLH_S)
+    hipLaunchKernelGGL((bf16_pack_kernel<float>), grid, dim3(256), 0, ctx().stream, (const float *)X, ldx, (float)scale,
+                       (unsigned short *)Y16, ldy, n);
+  else
+    hipLaunchKernelGGL((bf16_pack_kernel<double>), grid, dim3(256), 0, ctx().stream, (const double *)X, ldx, (float)scale,
+                       (unsigned short *)Y16, ldy, n);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+int rlh_bf16_unpack(int dst_dtype, int64_t n, int64_t m, const void *X16, int64_t ldx, void *Y, int64_t ldy) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dst_dtype == RLH_S || dst_dtype == RLH_D, "rlh_bf16_unpack: real blocks only");
+  RLH_REQUIRE(n >= 0 && m >= 0, "rlh_bf16_unpack: negative size");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(X16 && Y && ldx >= n && ldy >= n, "rlh_bf16_unpack: bad arguments");
+  dim3 grid(row_blocks(n, m), (unsigned)m);
+  if (dst_dtype == RLH_S)
+    hipLaunchKernelGGL((bf16_unpack_kernel<float>), grid, dim3(256), 0, ctx().stream, (const unsigned short *)X16, ldx,
+                       (float *)Y, ldy, n);
+  else
+    hipLaunchKernelGGL((bf16_unpack_kernel<double>), grid, dim3(256), 0, ctx().stream, (const unsigned short *)X16, ldx,
+                       (double *)Y, ldy, n);
   RLH_HIP(hipGetLastError());
   return 0;
 }

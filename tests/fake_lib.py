@@ -314,6 +314,11 @@ class FakeLib:
         return 0
 
     def rlh_csr_layout(self, h, layout, stored, ratio):
+        # (the stand-in has no device layout; it reports the windowed one so that the host logic
+        # that depends on it -- bfloat16 preconditioner storage -- is exercised on the CPU tier)
+        ctypes.cast(layout, ctypes.POINTER(ctypes.c_int))[0] = 1
+        ctypes.cast(stored, ctypes.POINTER(ctypes.c_int64))[0] = 0
+        ctypes.cast(ratio, ctypes.POINTER(ctypes.c_double))[0] = 0.0
         return 0
 
     def _rows_of_part(self, c, part, n_own):
@@ -363,6 +368,36 @@ class FakeLib:
         pv = _block(P, c.code, nr, m, ldp)
         new = cy * _block(Y, c.code, nr, m, ldy) + cp * pv + cb * (_block(B, c.code, nr, m, ldb) - t)
         pv[:, mask] = new[:, mask]
+        return 0
+
+    @staticmethod
+    def _bf16_block(ptr, n, m, ld):
+        flat = _flat(ptr, np.uint16, (m - 1) * ld + n)
+        return np.lib.stride_tricks.as_strided(flat, shape=(m, n), strides=(ld * 2, 2))
+
+    def rlh_bf16_pack(self, code, n, m, X, ldx, scale, Y16, ldy):
+        if n and m:
+            x = _block(X, code, n, m, ldx)
+            self._bf16_block(Y16, n, m, ldy)[:, :] = ops.bf16_bits(np.float32(scale) * x.astype(np.float32))
+        return 0
+
+    def rlh_bf16_unpack(self, code, n, m, X16, ldx, Y, ldy):
+        if n and m:
+            _block(Y, code, n, m, ldy)[:, :] = ops.bf16_from_bits(self._bf16_block(X16, n, m, ldx)).astype(_DT[code])
+        return 0
+
+    def rlh_spmm_cheb_bf16(self, h, m, Y16, ldy, P16, ldp, B16, ldb, cy, cp, cb):
+        self._count('spmm_cheb_bf16')
+        c = self._csr[_addr(h)]
+        nr = c.mat.shape[0]
+        if m == 0 or nr == 0:
+            return 0
+        y = ops.bf16_from_bits(self._bf16_block(Y16, nr, m, ldy))
+        pv = self._bf16_block(P16, nr, m, ldp)
+        b = ops.bf16_from_bits(self._bf16_block(B16, nr, m, ldb))
+        t = (c.mat.astype(np.float32) @ y.T).T
+        new = np.float32(cy) * y + np.float32(cp) * ops.bf16_from_bits(pv) + np.float32(cb) * (b - t)
+        pv[:, :] = ops.bf16_bits(new)
         return 0
 
     def rlh_dense_apply(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy):

@@ -264,3 +264,29 @@ def test_mixed_precision_chebyshev_preconditioner():
     assert status == 0
     assert np.max(np.abs(lmd[:6] - ana) / ana) < 1e-10
     assert partial_hevp.last['iterations'] < 60
+
+
+def test_bf16_storage_chebyshev_preconditioner():
+    """Preconditioner work blocks in bfloat16 (float32 arithmetic): same eigenvalues, about the same
+    iteration count as float32 storage."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip import SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
+    from raleigh_amd import _lib
+    from oracle.sparse import lap3d, lap3d_eigenvalues
+    A = lap3d(20, 19, 18, 1.0, 1.01, 1.02)
+    ana = lap3d_eigenvalues(20, 19, 18, 1.0, 1.01, 1.02, 6)
+    its = {}
+    for storage in (None, 'bf16'):
+        np.random.seed(1)
+        opt = Options()
+        opt.max_iter = 500
+        T = ChebyshevPreconditioner(None, gershgorin_upper_bound(A), ratio=100, degree=6,
+                                    low_precision_op=SparseSymmetricMatrix(A.astype(np.float32)), storage=storage)
+        lmd, x, status = partial_hevp(A, T=T, which=6, tol=1e-7, verb=-1, opt=opt)
+        assert status == 0
+        assert np.max(np.abs(lmd[:6] - ana) / ana) < 1e-10
+        its[storage] = partial_hevp.last['iterations']
+    assert _lib.library().calls.get('spmm_cheb_bf16', 0) > 10
+    assert its['bf16'] <= its[None] + 3

@@ -603,3 +603,53 @@ def test_absmax(key):
     want = max(np.max(np.abs(a.real)), np.max(np.abs(a.imag)))
     assert Matrix(a).absmax() == float(want)
     assert Matrix(np.asfortranarray(a)).absmax() == float(want)
+
+
+def test_bf16_pack_unpack_bit_exact():
+    """rlh_bf16_pack / unpack: round-to-nearest-even bit patterns identical to the oracle's."""
+    import ctypes
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    rng = np.random.default_rng(41)
+    n, m = 10007, 5
+    for dt in (np.float64, np.float32):
+        x = (rng.standard_normal((m, n)) * 10.0 ** rng.integers(-20, 20, (m, 1))).astype(dt)
+        x[0, :4] = [0.0, 1.0, 1.00390625, -3.0]                  # exact and tie cases
+        X = Vectors(x)
+        blk = Bf16Block(n, m)
+        blk.pack(X, 0.75)
+        Y = Vectors(n, m, data_type=dt)
+        blk.unpack(Y)
+        want = ops.bf16_round(np.float32(0.75) * x.astype(np.float32))
+        assert np.array_equal(Y.data(), want.astype(dt))
+
+
+@pytest.mark.parametrize('m', [1, 8, 13, 16, 32])
+def test_fused_chebyshev_step_bf16(m):
+    """rlh_spmm_cheb_bf16 against float32 NumPy on the SAME bfloat16 inputs: the only differences are
+    the summation order of the 7 products per row and one final rounding to bfloat16."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    A = lap3d(23, 19, 17, 1.0, 1.01, 1.02).astype(np.float32)
+    n = A.shape[0]
+    rng = np.random.default_rng(5 + m)
+    y0, p0, b0 = (ops.bf16_round(rng.standard_normal((m, n)).astype(np.float32)) for _ in range(3))
+    op = SparseSymmetricMatrix(A)
+    assert op.supports_bf16()
+    blocks = []
+    for a in (y0, p0, b0):
+        blk = Bf16Block(n, m)
+        blk.pack(Vectors(a), 1.0)
+        blocks.append(blk)
+    y, p, b = blocks
+    op.cheb_step_bf16(m, y, p, b, 1.3, -0.3, 0.01)
+    out = Vectors(n, m, data_type=np.float32)
+    p.unpack(out)
+    t = (sp.csr_matrix(A) @ y0.T).T.astype(np.float32)
+    exact = np.float32(1.3) * y0 + np.float32(-0.3) * p0 + np.float32(0.01) * (b0 - t)
+    got = out.data()
+    assert np.all(np.abs(got - exact) <= 2.0 ** -8 * np.abs(exact) + 1e-6)     # half a bf16 ulp + float32 noise
+    chk = Vectors(n, m, data_type=np.float32)
+    y.unpack(chk)
+    assert np.array_equal(chk.data(), y0)                                      # inputs untouched

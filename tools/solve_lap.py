@@ -14,6 +14,7 @@ ap.add_argument('--profile', action='store_true')
 ap.add_argument('--cheb', type=int, default=0, help='degree of the device Chebyshev preconditioner (0: none)')
 ap.add_argument('--ratio', type=float, default=100.0)
 ap.add_argument('--low', action='store_true', help='evaluate the preconditioner in float32')
+ap.add_argument('--bf16', action='store_true', help='with --low: keep the preconditioner work blocks in bfloat16')
 a = ap.parse_args()
 from raleigh_amd.interfaces import partial_hevp
 from raleigh_amd.core.solver import Options
@@ -34,7 +35,7 @@ if a.cheb > 0:
     from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
     low = SparseSymmetricMatrix(A.astype(np.float32)) if a.low else None
     T = ChebyshevPreconditioner(None if a.low else SparseSymmetricMatrix(A), gershgorin_upper_bound(A), ratio=a.ratio, degree=a.cheb,
-                                low_precision_op=low)
+                                low_precision_op=low, storage='bf16' if a.bf16 else None)
 lmd, x, status = partial_hevp(A, T=T, which=a.k, tol=a.tol, verb=a.verb, opt=opt)
 if a.profile:
     pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(35)
