@@ -168,11 +168,11 @@ def solve_ten(side, comm):
         op = ShardedSparseMatrix.from_local_rows(rows, r0, n, comm, off)
         op32 = ShardedSparseMatrix.from_local_rows(rows.astype(np.float32), r0, n, comm, off)
         vectors = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=off)
-    # device-resident Chebyshev polynomial preconditioner (degree 24 on [hi/10000, hi], hi = the
+    # device-resident Chebyshev polynomial preconditioner (degree 32 on [hi/7000, hi], hi = the
     # Gershgorin bound 4 (cx + cy + cz) of the stencil), evaluated in float32: every block stays in HBM
     hi = 4.0 * sum(((side + 1.0) / a) ** 2 for a in (1.0, 1.01, 1.02))
     # (work blocks in bfloat16 on one GPU; the sharded operator keeps float32 storage)
-    T = ChebyshevPreconditioner(None, hi, ratio=10000.0, degree=24, low_precision_op=op32, storage='bf16')
+    T = ChebyshevPreconditioner(None, hi, ratio=7000.0, degree=32, low_precision_op=op32, storage='bf16')
     t0 = time.perf_counter()
     lmd, x, status = partial_hevp(None, T=T, which=10, tol=1e-6, verb=-1, opt=opt, vectors=vectors,
                                   operator=op)
@@ -180,7 +180,7 @@ def solve_ten(side, comm):
     ana = lap3d_eigenvalues(side, side, side, 1.0, 1.01, 1.02, 10)
     err = float(np.max(np.abs(lmd[:10] - ana) / ana)) if status == 0 and len(lmd) >= 10 else None
     return {'problem': 'lap3d %d^3 (n=%d), 10 smallest eigenpairs, eigenvector tol 1e-6, device Chebyshev '
-                       'preconditioner (degree 24, float32 arithmetic, bfloat16 work blocks on one GPU), rows sharded over the ranks' % (side, n),
+                       'preconditioner (degree 32, float32 arithmetic, bfloat16 work blocks on one GPU), rows sharded over the ranks' % (side, n),
             'seconds': round(seconds, 3), 'status': int(status), 'iterations': int(partial_hevp.last['iterations']),
             'max_rel_eigenvalue_error': err}
 
