@@ -269,6 +269,42 @@ static int launch_spmm(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int
 // 215^3: centre + y neighbours in one window, the two z planes in one each) instead of once per
 // entry (7x), and the seven reads per row come out of the LDS.
 template <typename T> struct WellCfg { static constexpr int SMAX = sizeof(T) >= 16 ? 4 : 8; };   // <= 64 KiB per buffer
+
+// Entry storage of a block: slot t of thread l (row l of the block) lives in 16-byte pieces per
+// thread -- values [t / VPG][l][t % VPG] with VPG = 16 / sizeof(T) values per piece, positions
+// [t / 8][l][t % 8] -- so that a thread fetches its row's entries with a few 16-byte loads (one
+// 4- or 8-byte and one 2-byte load per entry cost as many vector-memory instructions as all the
+// staging of the block).  A block's slots are padded to a multiple of 8; eoff counts slots.
+template <typename T>
+__host__ __device__ inline int64_t well_val_index(int64_t eoff, int t, int l) {
+  constexpr int VPG = 16 / (int)sizeof(T) > 0 ? 16 / (int)sizeof(T) : 1;
+  return (eoff + (t / VPG) * VPG) * 1024 + (int64_t)l * VPG + (t % VPG);
+}
+__host__ __device__ inline int64_t well_idx_index(int64_t eoff, int t, int l) {
+  return (eoff + (t / 8) * 8) * 1024 + (int64_t)l * 8 + (t % 8);
+}
+typedef unsigned rlh_u32x4e __attribute__((ext_vector_type(4)));
+// the row's WMAX values and positions (positions beyond `width` and their values come back as 0)
+template <typename T, int WMAX>
+__device__ __forceinline__ void well_load_entries(const T *__restrict__ vals, const uint16_t *__restrict__ idx,
+                                                  int64_t eoff, int tid, int width, T (&v)[WMAX], unsigned (&pos)[WMAX]) {
+  constexpr int VPG = 16 / (int)sizeof(T) > 0 ? 16 / (int)sizeof(T) : 1;
+  static_assert(WMAX % 8 == 0 && WMAX % VPG == 0, "entry slots come in 16-byte pieces");
+#pragma unroll
+  for (int g = 0; g < WMAX / VPG; ++g) {
+    union { rlh_u32x4e u; T t[VPG]; } piece;
+    piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(vals + well_val_index<T>(eoff, g * VPG, tid)));
+#pragma unroll
+    for (int k = 0; k < VPG; ++k) v[g * VPG + k] = (g * VPG + k < width) ? piece.t[k] : zero_of(T{});
+  }
+#pragma unroll
+  for (int g = 0; g < WMAX / 8; ++g) {
+    union { rlh_u32x4e u; unsigned short h[8]; } piece;
+    piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(idx + well_idx_index(eoff, g * 8, tid)));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pos[g * 8 + k] = (g * 8 + k < width) ? (unsigned)piece.h[k] : 0u;
+  }
+}
 constexpr int kWellRows = 1024;
 
 // Exchange within a quad of lanes (DPP quad_perm): CTRL 0xB1 = lane ^ 1, 0x4E = lane ^ 2.
@@ -335,16 +371,15 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
     constexpr bool PACK = WMAX * sizeof(T) >= 256;
     T v[WMAX];
     unsigned ixb[PACK ? WMAX / 2 : WMAX];
+    {
+      unsigned px[WMAX];
+      well_load_entries<T, WMAX>(vals, idx, mt.eoff, tid, width, v, px);
 #pragma unroll
-    for (int t = 0; t < WMAX; ++t) {
-      const int64_t e = (mt.eoff + t) * kWellRows + tid;
-      const T val = nt_load(vals + e);
-      const unsigned pos_t = __builtin_nontemporal_load(idx + e);
-      v[t] = t < width ? val : zero_of(T{});
-      const unsigned px = t < width ? pos_t : 0u;
-      if constexpr (!PACK) ixb[t] = px * (unsigned)sizeof(T);
-      else if (t & 1) ixb[t / 2] |= px << 16;
-      else ixb[t / 2] = px;
+      for (int t = 0; t < WMAX; ++t) {
+        if constexpr (!PACK) ixb[t] = px[t] * (unsigned)sizeof(T);
+        else if (t & 1) ixb[t / 2] |= px[t] << 16;
+        else ixb[t / 2] = px[t];
+      }
     }
     auto entry_offset = [&](int t) -> unsigned {       // byte offset of entry t's column in a staged vector
       if constexpr (!PACK) return ixb[t];
@@ -569,14 +604,9 @@ __global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__
     const int64_t row = row0 + lane;
     float v[WMAX];
     unsigned ixb[WMAX];
+    well_load_entries<float, WMAX>(vals, idx, mt.eoff, tid, width, v, ixb);
 #pragma unroll
-    for (int t = 0; t < WMAX; ++t) {
-      const int64_t e = (mt.eoff + t) * kWellRows + tid;
-      const float val = __builtin_nontemporal_load(vals + e);
-      const unsigned pos_t = __builtin_nontemporal_load(idx + e);
-      v[t] = t < width ? val : 0.f;
-      ixb[t] = t < width ? pos_t * 2u : 0u;
-    }
+    for (int t = 0; t < WMAX; ++t) ixb[t] *= 2u;        // byte offset in the bfloat16 image
     // staging slots: 8 groups (one 16-byte piece per lane) each
     int sbase[SLOTS], scc[SLOTS], scol[SLOTS];
 #pragma unroll
@@ -1051,7 +1081,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   int64_t goff = 0;
   for (int64_t b = 0; b < nblocks; ++b) {
     meta[b] = WellMeta{eoff, (int32_t)goff, width[b] | (ngroups[b] << 8)};
-    eoff += width[b];
+    eoff += (width[b] + 7) / 8 * 8;                 // 16-byte pieces per thread: slots in multiples of 8
     goff += ngroups[b];
   }
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
@@ -1070,8 +1100,8 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     for (int l = 0; l < kWellRows; ++l) {
       const int64_t r = r0 + l;
       const int64_t p = r < n ? indptr[r] : 0, len = r < n ? indptr[r + 1] - p : 0;
-      for (int32_t t = 0; t < width[b]; ++t) {
-        const int64_t e = (meta[b].eoff + t) * kWellRows + l;
+      for (int32_t t = 0; t < (width[b] + 7) / 8 * 8; ++t) {
+        const int64_t ev = well_val_index<T>(meta[b].eoff, t, l), ei = well_idx_index(meta[b].eoff, t, l);
         if (t < len) {
           const int32_t c = indices[p + t];
           // last window starting at or before c
@@ -1080,11 +1110,11 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
             const size_t mid = (lo + hi) / 2;
             if (ws[mid].start <= c) lo = mid; else hi = mid;
           }
-          idx[e] = (uint16_t)(ws[lo].off + (c - ws[lo].start));
-          vals[e] = values[p + t];
+          idx[ei] = (uint16_t)(ws[lo].off + (c - ws[lo].start));
+          vals[ev] = values[p + t];
         } else {
-          idx[e] = 0;
-          memset(&vals[e], 0, sizeof(T));
+          idx[ei] = 0;
+          memset(&vals[ev], 0, sizeof(T));
         }
       }
     }
