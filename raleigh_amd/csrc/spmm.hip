@@ -641,6 +641,20 @@ __global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__
     auto compute = [&](int s) {
       unsigned boff = (unsigned)(s & 1) * (unsigned)kBfBufBytes;
       const int j0 = s * cps;
+      // after the row products, lane L takes vector j0 + L / 8, rows 8 (L % 8) .. + 7 of the wave's 64;
+      // its pieces of p, b, y are requested FIRST (from clamped, always valid addresses) so that
+      // their latency passes under the LDS work below instead of after it
+      const int c8 = lane >> 3, rg = lane & 7;
+      const int j = j0 + c8;
+      const int64_t r8 = row0 + rg * 8;
+      const bool mine = c8 < cps && j < m && r8 < n_rows;
+      const bool whole = mine && r8 + 8 <= n_rows;
+      const int jc = j < m ? j : m - 1;
+      const int64_t rc = whole ? r8 : 0;
+      unsigned short *pp = P + (int64_t)jc * ldp + rc;
+      const Bf8 pv = *reinterpret_cast<const Bf8 *>(pp);           // (the host checked 16-byte alignment)
+      const Bf8 bv = *reinterpret_cast<const Bf8 *>(B + (int64_t)jc * ldb + rc);
+      const Bf8 yv = *reinterpret_cast<const Bf8 *>(Yk + (int64_t)jc * ldy + rc);
       // (A y)[row] for the step's vectors -> the wave's tile
 #pragma unroll 1
       for (int c = 0; c < cps; ++c) {
@@ -654,34 +668,26 @@ __global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__
         }
         tile[c * 64 + lane] = acc;
       }
-      // lane L now takes vector j0 + L / 8, rows 8 (L % 8) .. + 7 of the wave's 64
-      const int c = lane >> 3, rg = lane & 7;
-      const int j = j0 + c;
-      const int64_t r8 = row0 + rg * 8;
+      const int ct = c8 < cps ? c8 : 0;
       float t8[8];
       {
-        const float4 lo = *reinterpret_cast<const float4 *>(tile + c * 64 + rg * 8);
-        const float4 hi = *reinterpret_cast<const float4 *>(tile + c * 64 + rg * 8 + 4);
+        const float4 lo = *reinterpret_cast<const float4 *>(tile + ct * 64 + rg * 8);
+        const float4 hi = *reinterpret_cast<const float4 *>(tile + ct * 64 + rg * 8 + 4);
         t8[0] = lo.x; t8[1] = lo.y; t8[2] = lo.z; t8[3] = lo.w;
         t8[4] = hi.x; t8[5] = hi.y; t8[6] = hi.z; t8[7] = hi.w;
       }
-      if (c < cps && j < m && r8 < n_rows) {
-        unsigned short *pp = P + (int64_t)j * ldp + r8;
-        const unsigned short *bp = B + (int64_t)j * ldb + r8, *yp = Yk + (int64_t)j * ldy + r8;
-        if (r8 + 8 <= n_rows) {
-          const Bf8 pv = *reinterpret_cast<const Bf8 *>(pp);       // (the host checked 16-byte alignment)
-          const Bf8 bv = *reinterpret_cast<const Bf8 *>(bp);
-          const Bf8 yv = *reinterpret_cast<const Bf8 *>(yp);
-          Bf8 out;
+      if (whole) {
+        Bf8 out;
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            out.e[k] = f32_to_bf16(cy * bf16_to_f32(yv.e[k]) + cp * bf16_to_f32(pv.e[k]) +
-                                   cb * (bf16_to_f32(bv.e[k]) - t8[k]));
-          *reinterpret_cast<Bf8 *>(pp) = out;
-        } else {                                   // the last rows of the matrix
-          for (int k = 0; k < 8 && r8 + k < n_rows; ++k)
-            pp[k] = f32_to_bf16(cy * bf16_to_f32(yp[k]) + cp * bf16_to_f32(pp[k]) + cb * (bf16_to_f32(bp[k]) - t8[k]));
-        }
+        for (int k = 0; k < 8; ++k)
+          out.e[k] = f32_to_bf16(cy * bf16_to_f32(yv.e[k]) + cp * bf16_to_f32(pv.e[k]) +
+                                 cb * (bf16_to_f32(bv.e[k]) - t8[k]));
+        *reinterpret_cast<Bf8 *>(pp) = out;
+      } else if (mine) {                           // the last rows of the matrix
+        unsigned short *pq = P + (int64_t)j * ldp + r8;
+        const unsigned short *bq = B + (int64_t)j * ldb + r8, *yq = Yk + (int64_t)j * ldy + r8;
+        for (int k = 0; k < 8 && r8 + k < n_rows; ++k)
+          pq[k] = f32_to_bf16(cy * bf16_to_f32(yq[k]) + cp * bf16_to_f32(pq[k]) + cb * (bf16_to_f32(bq[k]) - t8[k]));
       }
     };
     stage_load(0, stA);
