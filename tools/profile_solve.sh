@@ -3,7 +3,7 @@
 # preconditioner): rocprofv3 --kernel-trace --stats around tools/solve_lap.py.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/solve_prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/solve_lap.py --side ${SIDE:-215} --cheb 24 --ratio 10000 --low ${EXTRA:-} > $O/solve.log 2>&1 || { tail -5 $O/solve.log; exit 2; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/tools/solve_lap.py --side ${SIDE:-215} --cheb 32 --ratio 7000 --low ${EXTRA:---bf16} > $O/solve.log 2>&1 || { tail -5 $O/solve.log; exit 2; }
 tail -3 $O/solve.log
 python3 - <<'PY'
 import csv, glob, os
