@@ -653,3 +653,41 @@ def test_fused_chebyshev_step_bf16(m):
     chk = Vectors(n, m, data_type=np.float32)
     y.unpack(chk)
     assert np.array_equal(chk.data(), y0)                                      # inputs untouched
+
+
+def test_full_size_roofline_point_fp64():
+    """The BASELINE roofline point itself: n = 215^3 = 9 938 375 rows, m = 32, fp64, every block in
+    HBM (start block from the device generator, so the host only ever sees m x m results).
+    Size-independent checks: Gram symmetric with diag == dots and the trace of a U(-1,1) block;
+    linearity (X Q)^H Y = Q^H (X^H Y); the SpMM is self-adjoint, <A X, Y> = <X, A Y>, and maps a
+    constant vector to the row sums of the matrix."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    N, m = 215, 32
+    A = lap3d(N, N, N, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    np.random.seed(5)
+    X, Y, W, Z = (Vectors(n, m) for _ in range(4))
+    X.fill_random()
+    Y.fill_random()
+    G = X.dot(X)
+    d = X.dots(X)
+    assert cases.rel(G, G.T) < 1e-14 and cases.rel(np.diag(G), d) < 1e-13
+    assert abs(np.trace(G) / (n * m) - 1.0 / 3.0) < 1e-3                   # E[u^2] = 1/3 for U(-1, 1)
+    assert np.max(np.abs(G - np.diag(np.diag(G)))) < 1e-3 * np.max(np.diag(G))   # independent columns
+    Q = np.random.randn(m, m)
+    X.multiply(Q, W)
+    # dot(other)[i, j] = <other_i, self_j>: W = X Q  =>  W.dot(Y) = (X.dot(Y)) Q
+    assert cases.rel(W.dot(Y), X.dot(Y) @ Q) < 1e-12
+    op = SparseSymmetricMatrix(A)
+    op.apply(X, W)                                                          # W = A X
+    op.apply(Y, Z)                                                          # Z = A Y
+    assert cases.rel(W.dot(Y), Z.dot(X).T) < 1e-12                          # <y_i, A x_j> = <A y_i, x_j>
+    c = np.ones((2, n))
+    c[1] *= 3.0                                                             # (two vectors through the host: 160 MB)
+    C = Vectors(c)
+    R = Vectors(n, 2)
+    op.apply(C, R)
+    rows = np.asarray(A.sum(axis=1)).ravel()
+    got = R.data()
+    scale = np.max(np.abs(A.data))                  # interior row sums cancel to ~0: compare on the entries' scale
+    assert np.max(np.abs(got[0] - rows)) < 1e-13 * scale and np.max(np.abs(got[1] - 3.0 * rows)) < 3e-13 * scale
