@@ -691,3 +691,41 @@ def test_full_size_roofline_point_fp64():
     got = R.data()
     scale = np.max(np.abs(A.data))                  # interior row sums cancel to ~0: compare on the entries' scale
     assert np.max(np.abs(got[0] - rows)) < 1e-13 * scale and np.max(np.abs(got[1] - 3.0 * rows)) < 3e-13 * scale
+
+
+@pytest.mark.parametrize('key', ['d', 's'])
+def test_spmm_layouts_agree_on_a_large_irregular_matrix(monkeypatch, key):
+    """n = 3*10^5 rows, 1..27 entries per row (banded couplings of varying reach plus a few far
+    ones, empty rows): several hundred 1024-row blocks through the XCD-aware schedule, all three
+    register-slot variants of the windowed kernel -- against the sliced kernel, which does one
+    gather per entry and shares nothing with it beyond the CSR input."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    rng = np.random.default_rng(77)
+    n = 300007
+    reach = np.repeat(rng.integers(1, 14, n // 1000 + 1), 1000)[:n]          # couplings per row: 1 + 2 * reach
+    reach[5000:6000] = 0
+    rows = np.repeat(np.arange(n), 2 * reach + 1)
+    offs = np.concatenate([np.arange(-r, r + 1) * (1 + (i % 7)) for i, r in enumerate(reach)])
+    cols = np.clip(rows + offs, 0, n - 1)
+    A = sp.coo_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    keep = np.ones(n)
+    keep[7000:7100] = 0                                                         # empty rows
+    A = sp.csr_matrix(sp.diags(keep) @ A).astype(DT[key])
+    A.eliminate_zeros()
+    assert np.diff(A.indptr).max() <= 32 and np.diff(A.indptr).min() == 0
+    m = 12
+    x = rnd((m, n), key, rng)
+    X = Vectors(x)
+    out = {}
+    for fmt in ('sell', 'well'):
+        monkeypatch.setenv('RLH_SPMM_FORMAT', fmt)
+        op = CsrOperator(A)
+        assert op.layout()[0] == fmt
+        Y = Vectors(n, m, data_type=DT[key])
+        op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+        out[fmt] = Y.data()
+    assert cases.rel(out['well'], out['sell']) < (2e-6 if key == 's' else 1e-14)
+    i = rng.integers(0, n, 200)                                                 # and a sample of rows against SciPy
+    ref = (A[i] @ x.T).T
+    assert cases.rel(out['well'][:, i], ref) < (2e-6 if key == 's' else 1e-13)
