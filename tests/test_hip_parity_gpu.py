@@ -729,3 +729,29 @@ def test_spmm_layouts_agree_on_a_large_irregular_matrix(monkeypatch, key):
     i = rng.integers(0, n, 200)                                                 # and a sample of rows against SciPy
     ref = (A[i] @ x.T).T
     assert cases.rel(out['well'][:, i], ref) < (2e-6 if key == 's' else 1e-13)
+
+
+def test_new_entry_points_reject_bad_arguments(monkeypatch):
+    """Error behaviour of the extensions: a message, no launch."""
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    A = lap3d(12, 11, 10, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    op64 = CsrOperator(A)
+    X, Y = Vectors(n, 2), Vectors(n, 2)
+    with pytest.raises(_lib.RlhError, match='part must be'):
+        op64.apply_ptr(2, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), part=3)
+    blocks = [Bf16Block(n, 2) for _ in range(3)]
+    with pytest.raises(_lib.RlhError, match='float32 operator'):
+        op64.cheb_step_bf16(2, *blocks, 1.0, 0.0, 1.0)                       # float64 operator
+    monkeypatch.setenv('RLH_SPMM_FORMAT', 'sell')
+    op32s = CsrOperator(A.astype(np.float32))
+    with pytest.raises(_lib.RlhError, match='windowed layout'):
+        op32s.cheb_step_bf16(2, *blocks, 1.0, 0.0, 1.0)                      # sliced layout
+    monkeypatch.delenv('RLH_SPMM_FORMAT')
+    op32 = CsrOperator(A.astype(np.float32))
+    with pytest.raises(_lib.RlhError, match='P is updated in place|bad block pointers'):
+        op32.cheb_step_bf16(2, blocks[0], blocks[0], blocks[1], 1.0, 0.0, 1.0)   # p aliases y
+    with pytest.raises(_lib.RlhError, match='real blocks only'):
+        blocks[0].pack(Vectors(n, 2, data_type=np.complex128))
