@@ -120,19 +120,21 @@ class ChebyshevPreconditioner:
 
 
 class JacobiSweepILU:
-    """Incomplete LU preconditioner applied on the device (the counterpart of the
-    reference's ILUT apply, raleigh/algebra/sparse_mkl.py:122-140 -> mkl_wrap.py:279-347, which
-    runs two triangular solves per vector on the host).
+    """Incomplete factorisation preconditioner applied on the device (the counterpart
+    of the reference's ILUT apply, raleigh/algebra/sparse_mkl.py:122-140 -> mkl_wrap.py:279-347,
+    which runs two triangular solves per vector on the host).
 
-    The factors come from SciPy's ``spilu`` on the host, once (natural ordering, no pivoting); of
-    them L and the pivots D are kept (an incomplete L D L^H of the symmetric / Hermitian matrix).  The two triangular solves are replaced by `sweeps`
-    Jacobi iterations each -- u <- c - L_s u and v <- D^-1 u - (D^-1 U_s) v, L_s / U_s the strictly
-    triangular parts, D^-1 U_s := L_s^H -- every sweep one fused pass of the library's sparse kernel over the whole
-    n x m block (`cheb_step_ptr` with (cy, cp, cb) = (0, 0, 1): p = b - A y).  With the same number
-    of sweeps on both sides the operator is p(L_s^T) D^-1 p(L_s), symmetric positive definite for
-    a symmetric positive definite matrix with positive pivots, as the solver requires
-    (raleigh/interfaces/partial_hevp.py:41-49).  It is an approximation of the ILU solve (exact
-    after n sweeps), so iteration counts are its own."""
+    The factors come from SciPy's ``spilu`` on the host, once (natural ordering, no pivoting); L
+    and the pivots D are kept, i.e. an incomplete L D L^H of the symmetric / Hermitian matrix.
+    The two triangular solves are replaced by `sweeps` Jacobi iterations each,
+        u <- c - L_s u        and        v <- D^-1 u - L_s^H v        (L_s: strictly lower part of L),
+    every sweep one fused pass of the library's sparse kernel over the whole n x m block
+    (`cheb_step_ptr` with (cy, cp, cb) = (0, 0, 1): p = b - A y).  The operator applied is
+    p(L_s)^H D^-1 p(L_s) with p(t) = 1 - t + t^2 - ... (degree `sweeps`): Hermitian positive
+    definite for positive pivots, as the solver requires (raleigh/interfaces/partial_hevp.py:41-49),
+    and equal to the exact (L D L^H)^-1 after n sweeps.  K sweeps only see K dependency levels of
+    the factor, so for long chains (a 3-D stencil in natural order) it is a weak preconditioner;
+    iteration counts are its own."""
 
     def __init__(self, matrix, sweeps=4, drop_tol=1e-4, fill_factor=10.0):
         import scipy.sparse as scs
