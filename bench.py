@@ -79,6 +79,25 @@ class InnerIteration:
         out.append(AY.dot(Y))       # YAY   solver.py:1447
         return out
 
+    def all_ops(self, q):
+        """The whole per-iteration op mix as the reference's driver issues it (about 65
+        blocks of traffic + the SpMM): the headline plus 4 multiply, 7 add-with-matrix, 6 copies and
+        1 scale on the same blocks (solver.py:1609-1656, 1321-1381)."""
+        X, AX, Y, AY, Z, AZ, W = self.b
+        self.headline()
+        for src, dst in ((X, W), (AX, W), (Y, W), (AY, W)):
+            src.multiply(q, dst)                # new X / AX / Z / AZ from the Ritz coefficients
+        for dst, src in ((W, Y), (W, AY), (Y, Z), (AY, AZ), (Y, X), (AY, AX), (W, X)):
+            dst.add(src, 1.0, q)                # the second halves of the updates, orthogonalisations
+        for src, dst in ((W, Z), (W, AZ), (Y, W), (AY, W), (X, W), (AX, W)):
+            src.copy(dst)
+        Y.scale(np.full(Y.nvec(), 1.0))
+
+    @staticmethod
+    def all_ops_bytes(n, m, es, nnz):
+        B = n * m * es
+        return InnerIteration.headline_bytes(n, m, es, nnz)[0] + 4 * 2 * B + 7 * 3 * B + 6 * 2 * B + 2 * B
+
     @staticmethod
     def headline_bytes(n, m, es, nnz):
         B = n * m * es
@@ -290,6 +309,17 @@ def main():
     nbytes, parts = InnerIteration.headline_bytes(n, m, es, nnz)
     value = nbytes / (ms_per_step * 1e-3) / 1e9
 
+    # ---- the all-ops figure beside the headline (reported, not the metric): a few steps of the full mix
+    q = np.eye(m) + 1e-3 * np.random.default_rng(7).standard_normal((m, m))
+    it.all_ops(q)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        it.all_ops(q)
+    sync_all()
+    all_ms = (time.perf_counter() - t0) / 5 * 1e3
+    all_bytes = InnerIteration.all_ops_bytes(n, m, es, nnz)
+
     # ---- roofline of the dominant kernel (two-operand Gram), HIP events on the kernels' stream
     X, AX = blocks[0], blocks[1]
     ms = ctypes.c_float()
@@ -328,7 +358,10 @@ def main():
                                   % (side, side, nzg, n, side, m, nnz, world),
                       'n': n, 'm': m, 'nnz': nnz, 'algorithmic_bytes_per_step': nbytes,
                       'bytes_breakdown': parts},
-           'roofline': roofline}
+           'roofline': roofline,
+           'all_ops': {'ms_per_step': round(all_ms, 3), 'algorithmic_bytes_per_step': all_bytes,
+                       'gbs': round(all_bytes / (all_ms * 1e-3) / 1e9, 1),
+                       'what': 'headline + 4 multiply + 7 add(q) + 6 copy + 1 scale (the reference driver\'s per-iteration mix)'}}
     if args.solve_side > 0:
         try:
             out['solve'] = solve_ten(args.solve_side, comm)
