@@ -190,7 +190,7 @@ def solve_ten(side, comm):
     # device-resident Chebyshev polynomial preconditioner (degree 32 on [hi/7000, hi], hi = the
     # Gershgorin bound 4 (cx + cy + cz) of the stencil), evaluated in float32: every block stays in HBM
     hi = 4.0 * sum(((side + 1.0) / a) ** 2 for a in (1.0, 1.01, 1.02))
-    # (work blocks in bfloat16 on one GPU; the sharded operator keeps float32 storage)
+    # (work blocks in bfloat16, float32 arithmetic; row shards exchange 2-byte halo rows)
     T = ChebyshevPreconditioner(None, hi, ratio=7000.0, degree=32, low_precision_op=op32, storage='bf16')
     t0 = time.perf_counter()
     lmd, x, status = partial_hevp(None, T=T, which=10, tol=1e-6, verb=-1, opt=opt, vectors=vectors,
@@ -199,7 +199,7 @@ def solve_ten(side, comm):
     ana = lap3d_eigenvalues(side, side, side, 1.0, 1.01, 1.02, 10)
     err = float(np.max(np.abs(lmd[:10] - ana) / ana)) if status == 0 and len(lmd) >= 10 else None
     return {'problem': 'lap3d %d^3 (n=%d), 10 smallest eigenpairs, eigenvector tol 1e-6, device Chebyshev '
-                       'preconditioner (degree 32, float32 arithmetic, bfloat16 work blocks on one GPU), rows sharded over the ranks' % (side, n),
+                       'preconditioner (degree 32, float32 arithmetic, bfloat16 work blocks), rows sharded over the ranks' % (side, n),
             'seconds': round(seconds, 3), 'status': int(status), 'iterations': int(partial_hevp.last['iterations']),
             'max_rel_eigenvalue_error': err}
 

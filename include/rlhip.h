@@ -211,13 +211,20 @@ int rlh_spmm_cheb_part(rlh_csr_t h, int part, int64_t m, const void *Y, int64_t 
  * 16-byte aligned.  pack: Y16 = bf16(scale * X) (round to nearest even) from a float32 / float64
  * block; unpack: back to float32 / float64.  rlh_spmm_cheb_bf16 is rlh_spmm_cheb on three bf16
  * blocks with float32 arithmetic against a square float32 operator in the windowed layout
- * (single GPU; returns an error otherwise, the caller then stays in float32). */
+ * (returns an error otherwise, the caller then stays in float32). */
 int rlh_bf16_pack(int src_dtype, int64_t n, int64_t m, const void *X, int64_t ldx, double scale,
                   void *Y16, int64_t ldy);
 int rlh_bf16_unpack(int dst_dtype, int64_t n, int64_t m, const void *X16, int64_t ldx, void *Y,
                     int64_t ldy);
 int rlh_spmm_cheb_bf16(rlh_csr_t h, int64_t m, const void *Y16, int64_t ldy, void *P16, int64_t ldp,
                        const void *B16, int64_t ldb, double cy, double cp, double cb);
+/* The bfloat16 step on a row shard (n_own / H16 / part as in rlh_spmm_part; n_own and ldh multiples
+ * of 8), and the row packing of its halo exchange. */
+int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, int64_t ldy,
+                            int64_t n_own, const void *H16, int64_t ldh, void *P16, int64_t ldp,
+                            const void *B16, int64_t ldb, double cy, double cp, double cb);
+int rlh_gather_rows_bf16(int64_t nidx, const int64_t *d_idx, int64_t m, const void *X16,
+                         int64_t ldx, void *Out16, int64_t ldo);
 /* Packs rows for the halo exchange: Out[i, j] = X[idx[i], j], i < nidx, j < m;
  * idx: DEVICE int64 (built once per operator). */
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m,

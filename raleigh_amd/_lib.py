@@ -74,6 +74,9 @@ SIGNATURES = {
     'rlh_bf16_pack': [_int, _i64, _i64, _p, _i64, ctypes.c_double, _p, _i64],
     'rlh_bf16_unpack': [_int, _i64, _i64, _p, _i64, _p, _i64],
     'rlh_spmm_cheb_bf16': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double, ctypes.c_double, ctypes.c_double],
+    'rlh_spmm_cheb_bf16_part': [_p, _int, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double,
+                                ctypes.c_double, ctypes.c_double],
+    'rlh_gather_rows_bf16': [_i64, _p, _i64, _p, _i64, _p, _i64],
     'rlh_dense_apply': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64],
     'rlh_timer_start': [],
     'rlh_timer_stop': [ctypes.POINTER(ctypes.c_float)],

@@ -266,11 +266,11 @@ class ShardedSparseMatrix:
         own = (cols >= r0) & (cols < r1)
         halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
         owner = np.searchsorted(off, halo_cols, side='right') - 1
-        # local column numbering: own rows first, then the halo rows from a multiple of 4 on (the
-        # 1-3 columns in between are never referenced: they are the padding of the local block's
+        # local column numbering: own rows first, then the halo rows from a multiple of 8 on (the
+        # 1-7 columns in between are never referenced: they are the padding of the local block's
         # leading dimension), so that no 16-byte piece of the library's staging loads lies across
         # the own / halo boundary whatever the shard size
-        n_own_pad = -(-(r1 - r0) // 4) * 4
+        n_own_pad = -(-(r1 - r0) // 8) * 8
         new_idx = np.empty_like(cols)
         new_idx[own] = cols[own] - r0
         new_idx[~own] = n_own_pad + np.searchsorted(halo_cols, cols[~own])
@@ -278,6 +278,7 @@ class ShardedSparseMatrix:
                              shape=(r1 - r0, n_own_pad + halo_cols.size))
         self._n_own = r1 - r0
         self._n_halo = int(halo_cols.size)
+        self._ld_halo = -(-self._n_halo // 8) * 8        # leading dimension of the halo block (16-byte rows of bfloat16)
         self._op = CsrOperator(ext, n_own=n_own_pad)
         self._nnz = nnz_global
         # receive plan: contiguous runs of halo rows per owner
@@ -316,23 +317,28 @@ class ShardedSparseMatrix:
         if key not in self._bufs:
             c = self._comm
             ns = sum(cnt for _, _, cnt in self._send)
-            nr = self._n_halo
+            nr = self._ld_halo
             self._bufs[key] = (c.buffer(ns * m * es), c.buffer(nr * m * es), c.buffer(nr * m * es))
         return self._bufs[key]
 
     def _start_exchange(self, x):
         """Packs the rows the peers need and posts the sends / receives; returns what
         `_finish_exchange` needs, or None when nothing is off-shard."""
-        c, L = self._comm, _lib.lib()
-        m = x.nvec()
-        code, es = x._code, x._es
+        L = _lib.lib()
+        code, ptr, ld = x._code, x.data_ptr(), x.ld()
+        return self._start_exchange_raw(x.nvec(), x._es, lambda cnt, idx, out: _lib.check(
+            L.rlh_gather_rows(code, cnt, idx, x.nvec(), ptr, ld, out, cnt)))
+
+    def _start_exchange_raw(self, m, es, gather):
+        """`gather(count, device index list, packed output)` packs rows of the block being exchanged;
+        es: bytes per element (2 for the bfloat16 work blocks of the preconditioner)."""
+        c = self._comm
         if not (self._n_halo > 0 or self._send):
             return None
         sendbuf, recvbuf, halo = self._buffers(m, es)
         ops, soff, roff = [], 0, 0
         for p, didx, cnt in self._send:                   # pack the rows each peer needs
-            _lib.check(L.rlh_gather_rows(code, cnt, didx.data_ptr(), m, x.data_ptr(), x.ld(),
-                                         sendbuf.data_ptr() + soff, cnt))
+            gather(cnt, didx.data_ptr(), sendbuf.data_ptr() + soff)
             ops.append(c.dist.P2POp(c.dist.isend, sendbuf[soff:soff + cnt * m * es], p, group=c.group))
             soff += cnt * m * es
         for p, hs, cnt in self._recv:
@@ -352,11 +358,11 @@ class ShardedSparseMatrix:
             w.wait()
         roff = 0
         for p, hs, cnt in self._recv:                     # peer blocks (ld = cnt) -> one halo block (ld = n_halo)
-            _lib.check(L.rlh_copy2d(halo.data_ptr() + hs * es, self._n_halo * es,
+            _lib.check(L.rlh_copy2d(halo.data_ptr() + hs * es, self._ld_halo * es,
                                     recvbuf.data_ptr() + roff, cnt * es, cnt * es, m, 2))
             roff += cnt * m * es
         if self._n_halo > 0:
-            return halo.data_ptr(), self._n_halo
+            return halo.data_ptr(), self._ld_halo
         return None, 0
 
     def _exchange_halo(self, x):
@@ -368,7 +374,7 @@ class ShardedSparseMatrix:
         """The (not yet filled) halo block the interior pass may be handed."""
         if self._n_halo == 0:
             return None, 0
-        return self._buffers(x.nvec(), x._es)[2].data_ptr(), self._n_halo
+        return self._buffers(x.nvec(), x._es)[2].data_ptr(), self._ld_halo
 
     def apply(self, x, y):
         m = x.nvec()
@@ -387,6 +393,23 @@ class ShardedSparseMatrix:
         self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), hp, ldh, part=1)
         halo_ptr, ldh = self._finish_exchange(pending)
         self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh, part=2)
+
+    def supports_bf16(self):
+        return self._dtype == np.float32 and self._op.layout()[0] == 'well'
+
+    def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
+        """The fused step on bfloat16 work blocks (sparse.Bf16Block) of the local rows: the halo rows
+        travel as 2-byte elements, the exchange is overlapped with the interior rows as in apply()."""
+        L = _lib.lib()
+        pending = self._start_exchange_raw(m, 2, lambda cnt, idx, out: _lib.check(
+            L.rlh_gather_rows_bf16(cnt, idx, m, y.ptr(), y.ld, out, cnt)))
+        if pending is None:
+            self._op.cheb_step_bf16(m, y, p, b, cy, cp, cb)
+            return
+        hp = self._buffers(m, 2)[2].data_ptr() if self._n_halo else None
+        self._op.cheb_step_bf16(m, y, p, b, cy, cp, cb, hp, self._ld_halo, part=1)
+        halo_ptr, ldh = self._finish_exchange(pending)
+        self._op.cheb_step_bf16(m, y, p, b, cy, cp, cb, halo_ptr, ldh, part=2)
 
     def cheb_step(self, y, p, b, cy, cp, cb):
         """Fused step of the three-term Chebyshev semi-iteration on row-sharded blocks

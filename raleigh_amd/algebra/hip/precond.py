@@ -98,7 +98,7 @@ class ChebyshevPreconditioner:
 
     def _apply_bf16(self, x, y, m):
         from .sparse import Bf16Block
-        n = x.dimension()
+        n = x._vdim                                 # local rows (a row shard packs its own part)
         if self._work16 is None or self._work16[0].m < m or self._work16[0].n != n:
             self._work16 = [Bf16Block(n, m) for _ in range(3)]
         b, ua, ub = self._work16

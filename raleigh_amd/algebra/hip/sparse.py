@@ -75,9 +75,9 @@ class CsrOperator:
         """part 0: all rows; 1: the rows that need no halo column; 2: the others (rlh_spmm_part)."""
         _lib.check(_lib.lib().rlh_spmm_part(self._h, part, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
 
-    def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
-        _lib.check(_lib.lib().rlh_spmm_cheb_bf16(self._h, m, y.ptr(), y.ld, p.ptr(), p.ld, b.ptr(), b.ld,
-                                                 float(cy), float(cp), float(cb)))
+    def cheb_step_bf16(self, m, y, p, b, cy, cp, cb, halo_ptr=None, ldh=0, part=0):
+        _lib.check(_lib.lib().rlh_spmm_cheb_bf16_part(self._h, part, m, y.ptr(), y.ld, self._n_own, halo_ptr, ldh,
+                                                      p.ptr(), p.ld, b.ptr(), b.ld, float(cy), float(cp), float(cb)))
 
     def cheb_step_ptr(self, m, y, p, b, cy, cp, cb, halo_ptr=None, ldh=0, part=0):
         """p = cy y + cp p + cb (b - A y) in one pass (y, p, b: Vectors windows; p updated in place)."""

@@ -57,7 +57,7 @@ struct rlh_csr {
   int64_t well_sched_part_len[2];
   int well_grid_part[2];
   int well_inbounds;       // every staging group lies inside [0, n_cols)
-  int well_aligned;        // every staging group starts on a multiple of 4 columns
+  int well_aligned;        // every staging group starts on a multiple of 8 columns
 };
 
 namespace rlh {
@@ -579,6 +579,8 @@ __global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__
                                                               const float *__restrict__ vals, int64_t n_rows,
                                                               const int32_t *__restrict__ sched, int64_t sched_len,
                                                               const unsigned short *__restrict__ Yk, int64_t ldy,
+                                                              int64_t n_own, const unsigned short *__restrict__ H,
+                                                              int64_t ldh,
                                                               unsigned short *__restrict__ P, int64_t ldp,
                                                               const unsigned short *__restrict__ B, int64_t ldb,
                                                               int m, float cy, float cp, float cb) {
@@ -624,7 +626,9 @@ __global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__
       for (int i = 0; i < SLOTS; ++i) {
         int j = s * cps + scc[i];
         if (j > m - 1) j = m - 1;
-        st[i] = *reinterpret_cast<const Bf8U *>(Yk + (int64_t)j * ldy + scol[i]);
+        const int c = scol[i];                      // (pieces never lie across n_own: the host checked)
+        const unsigned short *src = c < n_own ? Yk + (int64_t)j * ldy + c : H + (int64_t)j * ldh + (c - n_own);
+        st[i] = *reinterpret_cast<const Bf8U *>(src);
       }
     };
     auto stage_write = [&](int s, const Bf8U (&st)[SLOTS]) {
@@ -1030,11 +1034,12 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
     std::vector<Win> &ws = wins[b];
     const int64_t nc = h->n_cols;
-    // 16-byte staging loads: a window starts on a multiple of 4 columns, and every 64-column group
+    // 16-byte staging loads: a window starts on a multiple of 8 columns (a piece is 2 to 8
+    // elements and must not lie across the own / halo boundary of a row shard), and every 64-column group
     // stays inside the column range where the matrix is wide enough (a window at the far end is
     // moved left instead of being padded past the last column)
     auto place = [&](int64_t first, int64_t last, int64_t &start, int64_t &padded) {
-      start = first & ~(int64_t)3;
+      start = first & ~(int64_t)7;
       padded = (last - start + 1 + 63) / 64 * 64;
       if (start + padded > nc && nc >= padded) start = nc - padded;
     };
@@ -1130,7 +1135,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   h->well_aligned = 1;
   for (int64_t g = 0; g < goff; ++g) {
     if ((int64_t)gsrc[g] + 64 > h->n_cols) h->well_inbounds = 0;
-    if (gsrc[g] & 3) h->well_aligned = 0;
+    if (gsrc[g] & 7) h->well_aligned = 0;
   }
   std::vector<int32_t> sched;
   well_schedule(wins, nblocks, n, ctx().num_cu, h->well_order);
@@ -1300,30 +1305,68 @@ int rlh_spmm_cheb(rlh_csr_t h, int64_t m, const void *Y, int64_t ldy, int64_t n_
   return rlh_spmm_cheb_part(h, 0, m, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, cy, cp, cb);
 }
 
-int rlh_spmm_cheb_bf16(rlh_csr_t h, int64_t m, const void *Y16, int64_t ldy, void *P16, int64_t ldp, const void *B16,
-                       int64_t ldb, double cy, double cp, double cb) {
+int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, int64_t ldy, int64_t n_own,
+                            const void *H16, int64_t ldh, void *P16, int64_t ldp, const void *B16, int64_t ldb,
+                            double cy, double cp, double cb) {
   if (int rc = require_ready()) return rc;
   RLH_REQUIRE(h != nullptr, "rlh_spmm_cheb_bf16: null handle");
+  RLH_REQUIRE(part >= 0 && part <= 2, "rlh_spmm_cheb_bf16: part must be 0 (all rows), 1 (interior) or 2 (boundary)");
   RLH_REQUIRE(m >= 0, "rlh_spmm_cheb_bf16: negative block size");
   if (m == 0 || h->n_rows == 0) return 0;
-  RLH_REQUIRE(h->dtype == RLH_S && h->well_blocks > 0 && h->well_inbounds && h->n_rows == h->n_cols,
-              "rlh_spmm_cheb_bf16: needs a square float32 operator in the windowed layout with every staging "
-              "group inside the column range");
+  RLH_REQUIRE(h->dtype == RLH_S && h->well_blocks > 0 && h->well_inbounds,
+              "rlh_spmm_cheb_bf16: needs a float32 operator in the windowed layout with every staging group inside "
+              "the column range");
+  RLH_REQUIRE(h->n_rows <= n_own && n_own <= h->n_cols, "rlh_spmm_cheb_bf16: the operator block must be square in its own rows");
+  RLH_REQUIRE(n_own == h->n_cols || (H16 && h->well_aligned && n_own % 8 == 0 && ldh % 8 == 0 && ((uintptr_t)H16 % 16) == 0),
+              "rlh_spmm_cheb_bf16: a halo block needs n_own and ldh to be multiples of 8, a 16-byte aligned block "
+              "and staging groups on multiples of 8 columns");
   RLH_REQUIRE(Y16 && P16 && B16 && P16 != Y16 && P16 != B16, "rlh_spmm_cheb_bf16: bad block pointers");
-  RLH_REQUIRE(ldy >= h->n_cols && ldp >= h->n_rows && ldb >= h->n_rows && ldy % 8 == 0 && ldp % 8 == 0 && ldb % 8 == 0 &&
+  RLH_REQUIRE(ldy >= n_own && ldp >= h->n_rows && ldb >= h->n_rows && ldy % 8 == 0 && ldp % 8 == 0 && ldb % 8 == 0 &&
                   ((uintptr_t)Y16 % 16) == 0 && ((uintptr_t)P16 % 16) == 0 && ((uintptr_t)B16 % 16) == 0,
               "rlh_spmm_cheb_bf16: blocks must be 16-byte aligned with leading dimensions that are multiples of 8");
   Context &c = ctx();
+  if (part != 0)
+    if (int rc = well_split(h, n_own)) return rc;
+  const int32_t *sched = part == 0 ? h->well_sched : h->well_sched_part[part - 1];
+  const int64_t sched_len = part == 0 ? h->well_sched_len : h->well_sched_part_len[part - 1];
+  const int64_t nb = part == 0 ? h->well_grid : h->well_grid_part[part - 1];
+  if (nb == 0) return 0;
   const unsigned short *Y = (const unsigned short *)Y16, *B = (const unsigned short *)B16;
+  const unsigned short *H = H16 ? (const unsigned short *)H16 : Y;
   unsigned short *P = (unsigned short *)P16;
 #define RLH_BF_LAUNCH(W)                                                                                          \
-  hipLaunchKernelGGL((well_cheb_bf16_kernel<W>), dim3((unsigned)h->well_grid), dim3(1024), 0, c.stream, h->well_meta, \
-                     h->well_gsrc, h->well_idx, (const float *)h->well_vals, h->n_rows, h->well_sched,            \
-                     h->well_sched_len, Y, ldy, P, ldp, B, ldb, (int)m, (float)cy, (float)cp, (float)cb)
+  hipLaunchKernelGGL((well_cheb_bf16_kernel<W>), dim3((unsigned)nb), dim3(1024), 0, c.stream, h->well_meta,       \
+                     h->well_gsrc, h->well_idx, (const float *)h->well_vals, h->n_rows, sched, sched_len, Y, ldy, \
+                     n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp, (float)cb)
   if (h->well_wmax <= 8) RLH_BF_LAUNCH(8);
   else if (h->well_wmax <= 16) RLH_BF_LAUNCH(16);
   else RLH_BF_LAUNCH(32);
 #undef RLH_BF_LAUNCH
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+int rlh_spmm_cheb_bf16(rlh_csr_t h, int64_t m, const void *Y16, int64_t ldy, void *P16, int64_t ldp, const void *B16,
+                       int64_t ldb, double cy, double cp, double cb) {
+  RLH_REQUIRE(h != nullptr, "rlh_spmm_cheb_bf16: null handle");
+  RLH_REQUIRE(h->n_rows == h->n_cols, "rlh_spmm_cheb_bf16: needs a square float32 operator (a row shard goes through "
+                                      "rlh_spmm_cheb_bf16_part)");
+  return rlh_spmm_cheb_bf16_part(h, 0, m, Y16, ldy, h->n_cols, nullptr, 0, P16, ldp, B16, ldb, cy, cp, cb);
+}
+
+int rlh_gather_rows_bf16(int64_t nidx, const int64_t *d_idx, int64_t m, const void *X16, int64_t ldx, void *Out16,
+                         int64_t ldo) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(nidx >= 0 && m >= 0, "rlh_gather_rows_bf16: negative size");
+  if (nidx == 0 || m == 0) return 0;
+  RLH_REQUIRE(d_idx && X16 && Out16 && ldo >= nidx, "rlh_gather_rows_bf16: bad arguments");
+  Context &c = ctx();
+  int64_t nb = (nidx + 255) / 256;
+  const int64_t cap = ((int64_t)c.num_cu * 8 + m - 1) / m;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((gather_rows_kernel<unsigned short>), dim3((unsigned)nb, (unsigned)m), dim3(256), 0, c.stream,
+                     d_idx, nidx, (const unsigned short *)X16, ldx, (unsigned short *)Out16, ldo);
   RLH_HIP(hipGetLastError());
   return 0;
 }

@@ -121,6 +121,14 @@ def main():
     assert status == 0, status
     assert np.max(np.abs(lmd3[:4] - ana) / ana) < 1e-10
     assert fake_lib_calls().get('convert', 0) > 10
+    # ... and with bfloat16 work blocks (the halo rows travel as 2-byte elements)
+    np.random.seed(1)
+    T = ChebyshevPreconditioner(None, gershgorin_upper_bound(A), ratio=100, degree=6, low_precision_op=op32,
+                                storage='bf16')
+    lmd4, x4, status = partial_hevp(None, T=T, which=4, tol=1e-8, verb=-1, opt=opt, vectors=mk, operator=op)
+    assert status == 0, status
+    assert np.max(np.abs(lmd4[:4] - ana) / ana) < 1e-10
+    assert fake_lib_calls().get('spmm_cheb_bf16', 0) > 10
 
     # row-sharded dense operator and PCA (BASELINE config 4 layout): same answer as one rank
     from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix

@@ -387,17 +387,35 @@ class FakeLib:
         return 0
 
     def rlh_spmm_cheb_bf16(self, h, m, Y16, ldy, P16, ldp, B16, ldb, cy, cp, cb):
+        ncol = self._csr[_addr(h)].mat.shape[1]
+        return self.rlh_spmm_cheb_bf16_part(h, 0, m, Y16, ldy, ncol, None, 0, P16, ldp, B16, ldb, cy, cp, cb)
+
+    def rlh_spmm_cheb_bf16_part(self, h, part, m, Y16, ldy, n_own, H16, ldh, P16, ldp, B16, ldb, cy, cp, cb):
         self._count('spmm_cheb_bf16')
         c = self._csr[_addr(h)]
-        nr = c.mat.shape[0]
+        nr, ncol = c.mat.shape
         if m == 0 or nr == 0:
             return 0
-        y = ops.bf16_from_bits(self._bf16_block(Y16, nr, m, ldy))
+        x = np.zeros((m, ncol), dtype=np.float32)
+        x[:, :n_own] = ops.bf16_from_bits(self._bf16_block(Y16, n_own, m, ldy))
+        if ncol > n_own and part != 1:
+            x[:, n_own:] = ops.bf16_from_bits(self._bf16_block(H16, ncol - n_own, m, ldh))
+        y = x[:, :nr]
         pv = self._bf16_block(P16, nr, m, ldp)
         b = ops.bf16_from_bits(self._bf16_block(B16, nr, m, ldb))
-        t = (c.mat.astype(np.float32) @ y.T).T
+        t = (c.mat.astype(np.float32) @ x.T).T
         new = np.float32(cy) * y + np.float32(cp) * ops.bf16_from_bits(pv) + np.float32(cb) * (b - t)
-        pv[:, :] = ops.bf16_bits(new)
+        mask = self._rows_of_part(c, part, n_own)
+        pv[:, mask] = ops.bf16_bits(new)[:, mask]
+        return 0
+
+    def rlh_gather_rows_bf16(self, nidx, d_idx, m, X16, ldx, Out16, ldo):
+        self._count('gather_rows')
+        if nidx == 0 or m == 0:
+            return 0
+        idx = _flat(d_idx, np.int64, nidx)
+        x = self._bf16_block(X16, int(idx.max()) + 1, m, ldx)
+        self._bf16_block(Out16, nidx, m, ldo)[:, :] = x[:, idx]
         return 0
 
     def rlh_dense_apply(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy):

@@ -755,3 +755,51 @@ def test_new_entry_points_reject_bad_arguments(monkeypatch):
         op32.cheb_step_bf16(2, blocks[0], blocks[0], blocks[1], 1.0, 0.0, 1.0)   # p aliases y
     with pytest.raises(_lib.RlhError, match='real blocks only'):
         blocks[0].pack(Vectors(n, 2, data_type=np.complex128))
+
+
+@pytest.mark.parametrize('rows', [(20000, 44000), (20003, 43998)])
+def test_fused_chebyshev_step_bf16_row_shard(rows):
+    """rlh_spmm_cheb_bf16_part on a row shard: own columns from y, the rest from a bfloat16 halo block;
+    part 1 (handed NaNs for the halo) + part 2 = the full step; against float32 NumPy on the same
+    bfloat16 inputs."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    A = lap3d(40, 40, 40, 1.0, 1.01, 1.02).astype(np.float32)
+    n = A.shape[0]
+    r0, r1 = rows
+    loc = sp.csr_matrix(A[r0:r1])
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    nown = r1 - r0
+    n_own_pad = -(-nown // 8) * 8
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(nown)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr), shape=(nown, n_own_pad + len(halo)))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    assert op.layout()[0] == 'well'
+    rng = np.random.default_rng(3)
+    m = 12
+    y0 = ops.bf16_round(rng.standard_normal((m, n)).astype(np.float32))
+    p0, b0 = (ops.bf16_round(rng.standard_normal((m, nown)).astype(np.float32)) for _ in range(2))
+
+    def block(a, rows_alloc):
+        blk = Bf16Block(rows_alloc, m)
+        pad = np.zeros((m, rows_alloc), dtype=np.float32)
+        pad[:, :a.shape[1]] = a
+        blk.pack(Vectors(pad), 1.0)
+        return blk
+    nh = -(-len(halo) // 8) * 8
+    y, p, b = block(y0[:, r0:r1], n_own_pad), block(p0, n_own_pad), block(b0, n_own_pad)
+    hgood = block(y0[:, halo], nh)
+    hbad = block(np.full((m, len(halo)), np.nan, dtype=np.float32), nh)
+    op.cheb_step_bf16(m, y, p, b, 1.3, -0.3, 0.01, hbad.ptr(), hbad.ld, part=1)
+    op.cheb_step_bf16(m, y, p, b, 1.3, -0.3, 0.01, hgood.ptr(), hgood.ld, part=2)
+    out = Vectors(n_own_pad, m, data_type=np.float32)
+    p.unpack(out)
+    t = (sp.csr_matrix(A[r0:r1]) @ y0.T).T.astype(np.float32)
+    exact = np.float32(1.3) * y0[:, r0:r1] + np.float32(-0.3) * p0 + np.float32(0.01) * (b0 - t)
+    got = out.data()[:, :nown]
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - exact) <= 2.0 ** -8 * np.abs(exact) + 1e-6)
