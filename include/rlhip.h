@@ -166,8 +166,8 @@ int rlh_conj(int dtype, int64_t n, int64_t m, void *X, int64_t ldx);
  *      (sparse_mkl.py:16-48; mkl_wrap.py:204-276 mkl_?csrmm 'SUNF'/'HUNF')
  * The caller passes the FULL matrix (both triangles) as 0-based CSR in host
  * memory; rows [row0, row0+n_rows) of a matrix with n_cols columns (row-shard
- * of the operator).  The library converts to a sliced-ELL or windowed-ELL device
- * layout (rlh_csr_layout).
+ * of the operator).  The library converts to one of three device layouts
+ * (rlh_csr_layout).
  * Y[:, j] = A * X[:, j]; X has n_cols rows, Y has n_rows rows. */
 typedef struct rlh_csr *rlh_csr_t;
 int rlh_csr_create(rlh_csr_t *h, int dtype, int64_t n_rows, int64_t n_cols,
@@ -177,10 +177,12 @@ int rlh_csr_destroy(rlh_csr_t h);
 int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
                  int64_t *device_bytes);
 /* Device layout the library chose for the handle (diagnostic): *layout = 0 sliced ELL
- * (one gather per stored entry and vector), 1 windowed ELL (the column windows of every
- * 1024-row block are staged through the LDS; chosen when the matrix has column locality);
+ * (one gather per stored entry and vector: no column locality), 1 windowed ELL (rows of at most
+ * 8 entries of a real type: the column windows of every 1024-row block are staged through the
+ * LDS, the row's entries stay in registers), 2 interleaved windowed layout (any row length, any
+ * type: 256-row blocks, LDS image [column][vector], entries streamed in chunks of 8);
  * *stored = entry slots incl. padding; *staged_per_slot = staged vector elements per entry
- * slot (windowed-layout analysis; 0 if it was not run).  RLH_SPMM_FORMAT=sell|well in the
+ * slot (windowed-layout analysis; 0 if it was not run).  RLH_SPMM_FORMAT=sell|well|wide in the
  * environment of rlh_csr_create overrides the choice. */
 int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per_slot);
 /* Columns [0, n_own) are read from X, columns [n_own, n_cols) from the halo block

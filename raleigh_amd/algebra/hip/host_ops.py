@@ -82,7 +82,20 @@ class SparseSymmetricSolver:
         self.solve(b, x)
 
     def inertia(self):
-        d = np.real(self._lu.U.diagonal())
+        """(negative, positive) eigenvalue counts of A - sigma B from the signs of diag(U).
+
+        Only valid when SuperLU kept the symmetric pivot order (perm_r == perm_c), so that
+        U = D L^H: `diag_pivot_thresh=0` still interchanges rows off an exactly zero diagonal
+        (saddle-point or unluckily shifted matrices), and then the sign count is not the inertia.
+        That case, and a zero pivot, raise -- partial_hevp maps them to status -1 like the
+        reference's "factorization too inaccurate" exit (partial_hevp.py:147-156)."""
+        lu = self._lu
+        if not np.array_equal(lu.perm_r, lu.perm_c):
+            raise RuntimeError('unsymmetric pivoting in the factorization of A - sigma B: inertia unavailable, '
+                               'consider moving the shift slightly')
+        d = np.real(lu.U.diagonal())
+        if np.any(d == 0) or not np.all(np.isfinite(d)):
+            raise RuntimeError('zero pivot in the factorization of A - sigma B: consider moving the shift slightly')
         neg = int(np.sum(d < 0))
         return neg, int(self._n - neg)
 

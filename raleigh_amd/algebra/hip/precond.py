@@ -56,7 +56,8 @@ class ChebyshevPreconditioner:
             self._apply_bf16(x, y, m)
             return
         nwork = 3 if self._low else 2
-        if self._work is None or self._work[0].nvec() < m or self._work[0].dimension() != x.dimension():
+        # (capacity = shape()[0]: nvec() is the current selection and shrinks with the solver's block)
+        if self._work is None or self._work[0].shape()[0] < m or self._work[0].dimension() != x.dimension():
             dt = None
             if self._low:
                 dt = np.complex64 if x.is_complex() else np.float32
@@ -176,7 +177,7 @@ class JacobiSweepILU:
 
     def apply(self, x, y):
         m = x.nvec()
-        if self._work is None or self._work[0].nvec() < m or self._work[0].dimension() != x.dimension():
+        if self._work is None or self._work[0].shape()[0] < m or self._work[0].dimension() != x.dimension():
             self._work = [x.new_vectors(m) for _ in range(3)]
             for w in self._work:
                 w.zero()                             # the fused step multiplies the old contents by 0

@@ -65,11 +65,11 @@ class CsrOperator:
         return self._dtype
 
     def layout(self):
-        """('sell' | 'well', stored entry slots, staged elements per slot): the device layout the
-        library chose (rlh_csr_layout)."""
+        """('sell' | 'well' | 'wide', stored entry slots, staged elements per slot): the device layout
+        the library chose (rlh_csr_layout)."""
         lay, stored, ratio = ctypes.c_int(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(_lib.lib().rlh_csr_layout(self._h, ctypes.byref(lay), ctypes.byref(stored), ctypes.byref(ratio)))
-        return ('well' if lay.value == 1 else 'sell'), int(stored.value), float(ratio.value)
+        return ('sell', 'well', 'wide')[lay.value], int(stored.value), float(ratio.value)
 
     def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0, part=0):
         """part 0: all rows; 1: the rows that need no halo column; 2: the others (rlh_spmm_part)."""

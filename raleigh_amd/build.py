@@ -5,6 +5,7 @@ hipcc cross-compiles without a GPU; the resulting .so is git-ignored but
 travels with the tree to the GPU box.
 """
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,24 +16,41 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'librlhip.so')
-SOURCES = ['context', 'gram', 'update', 'spmm', 'dense']
+SOURCES = ['context', 'gram', 'update', 'spmm', 'spmm_wide_build', 'spmm_wide_s', 'spmm_wide_d', 'spmm_wide_c',
+           'spmm_wide_z', 'dense']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
 
-def _newest_source_mtime():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+HASHPATH = LIBPATH + '.srchash'
+
+
+def source_hash():
+    """sha256 over the compile flags and every file the library is built from (file name + bytes)."""
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
     files.append(os.path.join(ROOT, 'include', 'rlhip.h'))
-    return max(os.path.getmtime(f) for f in files)
+    h = hashlib.sha256(' '.join(FLAGS + SOURCES).encode())
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def is_up_to_date():
-    return os.path.exists(LIBPATH) and os.path.getmtime(LIBPATH) >= _newest_source_mtime()
+    """The shipped .so was built from exactly these sources and flags (hash recorded by the build that
+    linked it; file times say nothing on a box that received the tree as a snapshot)."""
+    if not (os.path.exists(LIBPATH) and os.path.exists(HASHPATH)):
+        return False
+    with open(HASHPATH) as fh:
+        return fh.read().strip() == source_hash()
 
 
 def build_library(force=False, verbose=False):
     """Compiles every csrc/*.hip for gfx950 and links lib/librlhip.so."""
     if not force and is_up_to_date():
         return LIBPATH
+    if os.path.exists(HASHPATH):
+        os.remove(HASHPATH)
     hipcc = os.environ.get('HIPCC', 'hipcc')
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, 'obj')
@@ -56,6 +74,8 @@ def build_library(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])
+    with open(HASHPATH, 'w') as fh:
+        fh.write(source_hash() + '\n')
     return LIBPATH
 
 

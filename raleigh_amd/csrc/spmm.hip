@@ -3,83 +3,21 @@
 // The reference keeps triu(A) in 1-based CSR and calls mkl_?csrmm with the
 // 'SUNF'/'HUNF' descriptor on the column-major n x m block
 // (raleigh/algebra/sparse_mkl.py:16-48, raleigh/algebra/mkl_wrap.py:204-276).
-// Here the caller hands over the FULL 0-based CSR (both triangles); at creation
-// it is re-laid-out on the host as sliced ELLPACK with slice height 64 (one
-// wavefront per slice, one lane per row): within a slice the entries are stored
-// column-major, so the value and column-index loads of a wave are perfectly
-// coalesced.  Each lane keeps JT accumulators (one per vector of the block) and,
-// per stored entry, gathers X[col, j] for the JT vectors: for banded / stencil /
-// FE matrices neighbouring rows reference neighbouring columns, so these gathers
-// are coalesced across the wave and re-use lines through L2 / Infinity Cache.
-// The kernel is HBM-bound: nnz*(s+4) matrix bytes + one read of X + one write of Y.
-#include <stdlib.h>
-
-#include <algorithm>
-#include <atomic>
-#include <thread>
-#include <vector>
-
-#include "common.h"
-
-// Per-block record of the windowed layout (see "Windowed ELL" below).
-struct WellMeta {
-  int64_t eoff;            // first entry slot of the block, in units of 1024 entries
-  int32_t goff;            // first staging group of the block in `gsrc`
-  int32_t width_ng;        // entry slots per row (low 8 bits) | staging groups per vector << 8
-};
-
-struct rlh_csr {
-  int dtype;
-  int64_t n_rows, n_cols, nnz;
-  int64_t n_slices;
-  int64_t padded;          // stored entries incl. padding
-  int64_t *slice_ptr;      // device, n_slices + 1 (entry offsets)
-  int32_t *cols;           // device, padded
-  void *vals;              // device, padded
-  int64_t device_bytes;
-  // windowed layout (used instead of the sliced one when the matrix has column locality)
-  int64_t well_blocks;     // 0: not built
-  int well_wmax;           // 8 / 16 / 32: register slots per row the kernel is instantiated for
-  WellMeta *well_meta;     // device, well_blocks
-  int32_t *well_gsrc;      // device: first column of every 64-entry staging group
-  uint16_t *well_idx;      // device: position of the entry's column in the staged image
-  void *well_vals;         // device
-  double well_ratio;       // staged elements per stored entry slot (diagnostic)
-  int32_t *well_sched;     // device: block processed at launch position p (-1: none)
-  int64_t well_sched_len;
-  int well_grid;           // workgroups the schedule was laid out for
-  // split of the blocks by "references a column >= n_own" (overlap of the halo exchange with the
-  // interior rows, rlh_spmm_part): host-side order / largest referenced column per block, and the
-  // two launch orders built on first use for a given n_own
-  std::vector<int32_t> well_order, well_maxcol;
-  int64_t well_split_at;   // n_own the split was built for (-1: none)
-  int32_t *well_sched_part[2];
-  int64_t well_sched_part_len[2];
-  int well_grid_part[2];
-  int well_inbounds;       // every staging group lies inside [0, n_cols)
-  int well_aligned;        // every staging group starts on a multiple of 8 columns
-};
+// Here the caller hands over the FULL 0-based CSR (both triangles); at creation it is re-laid-out
+// on the host in one of three device layouts (rlh_csr_layout reports which):
+//  * 1024-row windowed ELL (this file, well_spmm_kernel): rows of at most 8 entries of a real
+//    type with column locality -- stencils.  A block's column windows are staged through the LDS,
+//    the row's entries stay in registers for all vectors.  Measured 54.6 % of the 8 TB/s peak on
+//    the 7-point Laplacian at n = 10^7, m = 32 (1.21 x the algorithmic traffic).
+//  * 256-row interleaved windowed layout (spmm_wide.inc): any row length, any type, with column
+//    locality -- FE matrices, wide bands, all complex operators.  Entries stream through registers
+//    in chunks of 8, the LDS image is [column][vector].
+//  * sliced ELLPACK, slice height 64 (sell_spmm_kernel): no column locality.  One 8-byte gather of
+//    X per stored entry and vector; limited by the rate at which a CU retires per-lane gathers
+//    (profiles/r01_spmm_sweep2.txt), not by HBM: 34 % on the 7-point Laplacian.
+#include "spmm.h"
 
 namespace rlh {
-
-__device__ __forceinline__ float nt_load(const float *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ double nt_load(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ c32 nt_load(const c32 *p) {
-  return c32{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
-}
-__device__ __forceinline__ c64 nt_load(const c64 *p) {
-  return c64{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
-}
-__device__ __forceinline__ void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void nt_store(double *p, double v) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void nt_store(c32 *p, c32 v) {
-  __builtin_nontemporal_store(v.re, &p->re);
-  __builtin_nontemporal_store(v.im, &p->im);
-}
-__device__ __forceinline__ void nt_store(c64 *p, c64 v) {
-  __builtin_nontemporal_store(v.re, &p->re);
-  __builtin_nontemporal_store(v.im, &p->im);
-}
 
 // Work mapping (speed only; any placement gives the same result).  Workgroups b and b + 8
 // share an XCD and its 4 MiB L2 under the observed round-robin placement.
@@ -98,21 +36,6 @@ __device__ __forceinline__ void nt_store(c64 *p, c64 v) {
 // updated in place; it must not alias y, which other rows are still gathering.  Per element the
 // step reads y, p, b and writes p (the two-term form with a residual and a direction block read
 // three and wrote three).
-template <typename T>
-struct ChebArgs {
-  const T *B; int64_t ldb;
-  double cy, cp, cb;
-};
-
-__device__ __forceinline__ float  scale_of(double s, float v)  { return (float)s * v; }
-__device__ __forceinline__ double scale_of(double s, double v) { return s * v; }
-__device__ __forceinline__ c32 scale_of(double s, c32 v) { return c32{(float)s * v.re, (float)s * v.im}; }
-__device__ __forceinline__ c64 scale_of(double s, c64 v) { return c64{s * v.re, s * v.im}; }
-__device__ __forceinline__ float  sub_of(float a, float b)   { return a - b; }
-__device__ __forceinline__ double sub_of(double a, double b) { return a - b; }
-__device__ __forceinline__ c32 sub_of(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ c64 sub_of(c64 a, c64 b) { return c64{a.re - b.re, a.im - b.im}; }
-
 template <typename T, int JT, int TT, bool CHEB>
 __global__ __launch_bounds__(256, (JT * TT >= 64 ? 1 : 2)) void sell_spmm_kernel(const int64_t *__restrict__ slice_ptr,
                                                         const int32_t *__restrict__ cols,
@@ -199,26 +122,22 @@ __global__ __launch_bounds__(256, (JT * TT >= 64 ? 1 : 2)) void sell_spmm_kernel
   }
 }
 
-static int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
-
 template <typename T, int JT, int TT>
 static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
                        T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
   Context &c = ctx();
-  static int per_cu = 0;
-  if (per_cu == 0) {
+  static int fit = 0;                                        // resident workgroups per CU of this instantiation
+  if (fit == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sell_spmm_kernel<T, JT, TT, false>, 256, 0) != hipSuccess || nb < 1)
       nb = 1;
-    per_cu = nb > 8 ? 8 : nb;
-    const int cap = env_int("RLH_SPMM_WG_PER_CU", 2);       // 0: as many as fit (tunable; 2 measured best)
-    if (cap > 0 && per_cu > cap) per_cu = cap;
+    fit = nb > 8 ? 8 : nb;
   }
-  static const int chunk = env_int("RLH_SPMM_CHUNK", 64);      // slices per row chunk (tunable)
-  static const int tpb_cap = env_int("RLH_SPMM_TPB", 1);       // waves of a workgroup on one slice (tunable)
+  int per_cu = fit;
+  const int cap = env_int("RLH_SPMM_WG_PER_CU", 2);         // 0: as many as fit (tunable; 2 measured best)
+  if (cap > 0 && per_cu > cap) per_cu = cap;
+  const int chunk = env_int("RLH_SPMM_CHUNK", 64);      // slices per row chunk (tunable)
+  const int tpb_cap = env_int("RLH_SPMM_TPB", 1);       // waves of a workgroup on one slice (tunable)
   const int ntiles = (int)((m + JT - 1) / JT);
   int tiles_per_block = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
   if (tiles_per_block > tpb_cap) tiles_per_block = tpb_cap >= 2 ? 2 : 1;
@@ -242,7 +161,7 @@ static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, i
 template <typename T, int JT>
 static int launch_spmm(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
                        T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
-  static const int tt = env_int("RLH_SPMM_TT", 1);             // entries per register group (tunable)
+  const int tt = env_int("RLH_SPMM_TT", 1);             // entries per register group (tunable)
   if (tt >= 8) return launch_spmm_t<T, JT, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if (tt >= 4) return launch_spmm_t<T, JT, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   return launch_spmm_t<T, JT, 1>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
@@ -283,7 +202,6 @@ __host__ __device__ inline int64_t well_val_index(int64_t eoff, int t, int l) {
 __host__ __device__ inline int64_t well_idx_index(int64_t eoff, int t, int l) {
   return (eoff + (t / 8) * 8) * 1024 + (int64_t)l * 8 + (t % 8);
 }
-typedef unsigned rlh_u32x4e __attribute__((ext_vector_type(4)));
 // the row's WMAX values and positions (positions beyond `width` and their values come back as 0)
 template <typename T, int WMAX>
 __device__ __forceinline__ void well_load_entries(const T *__restrict__ vals, const uint16_t *__restrict__ idx,
@@ -317,11 +235,6 @@ __device__ __forceinline__ T dpp_quad(T v) {
   for (int k = 0; k < W; ++k) b.w[k] = __builtin_amdgcn_update_dpp(0, a.w[k], CTRL, 0xf, 0xf, true);
   return b.t;
 }
-
-// 16-byte pieces of a block of vectors: natural alignment of T on the global side (a group may
-// start on any column), 16 bytes on the LDS side.
-template <typename T, int EPL> struct VecU { T e[EPL]; };
-template <typename T, int EPL> struct alignas(16) VecA { T e[EPL]; };
 
 template <typename T, int WMAX, int EPL, bool CHEB>
 __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restrict__ meta,
@@ -494,9 +407,9 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
         boff += (unsigned)F * (unsigned)sizeof(T);
       }
     };
-    if constexpr (PACK) {
-      // 32 entry slots of an 8-byte type leave room for one register set only: the loads of step
-      // s + 1 are in flight during the arithmetic of step s
+    if constexpr (PACK || EPL == 1) {
+      // one register set only (the element-wise staging of unaligned layouts needs SMAX slots per
+      // set): the loads of step s + 1 are in flight during the arithmetic of step s
       stage_load(0, stA);
       stage_write(0, stA);
       __syncthreads();
@@ -741,7 +654,7 @@ static int launch_well_we(const rlh_csr *h, int part, int64_t m, const T *X, int
   const int64_t sched_len = part == 0 ? h->well_sched_len : h->well_sched_part_len[part - 1];
   const int64_t nb = part == 0 ? h->well_grid : h->well_grid_part[part - 1];   // one workgroup per CU, persistent
   if (nb == 0) return 0;
-  static const int cps_cap = env_int("RLH_SPMM_CPS", 8);       // vectors per step (tunable)
+  const int cps_cap = env_int("RLH_SPMM_CPS", 8);       // vectors per step (tunable)
   if (cheb)
     hipLaunchKernelGGL((well_spmm_kernel<T, WMAX, EPL, true>), dim3((unsigned)nb), dim3(1024), 0, c.stream,
                        h->well_meta, h->well_gsrc, h->well_idx, (const T *)h->well_vals, h->n_rows, h->n_cols,
@@ -764,7 +677,7 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
   // piece); the addresses themselves only need T's alignment
   constexpr int EPL = 16 / (int)sizeof(T);
   if constexpr (EPL > 1) {
-    static const int vec = env_int("RLH_SPMM_VEC", 1);         // 0: 8-byte staging (tunable)
+    const int vec = env_int("RLH_SPMM_VEC", 1);         // 0: 8-byte staging (tunable)
     const bool whole = h->well_inbounds && (H == nullptr || n_own == h->n_cols || (h->well_aligned && n_own % EPL == 0));
     if (vec && whole) return launch_well_we<T, WMAX, EPL>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   }
@@ -774,10 +687,8 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
 template <typename T>
 static int launch_well(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
                        int64_t ldh, T *Y, int64_t ldy, const ChebArgs<T> *cheb) {
-  if (h->well_wmax <= 8) return launch_well_w<T, 8>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
-  if constexpr (sizeof(T) <= 8)               // 32 register slots of a 16-byte type would spill
-    if (h->well_wmax > 16) return launch_well_w<T, 32>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
-  return launch_well_w<T, 16>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  // (rows of more than 8 entries and the complex types use the interleaved layout, spmm_wide.inc)
+  return launch_well_w<T, 8>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 
 static int well_split(rlh_csr *h, int64_t n_own);
@@ -792,13 +703,23 @@ static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ld
   T *Y = (T *)Y_;
   ChebArgs<T> cargs{(const T *)B_, ldb, cy, cp, cb};
   const ChebArgs<T> *cheb = B_ ? &cargs : nullptr;
-  if (h->well_blocks > 0) {
-    if (part != 0)
-      if (int rc = well_split(h, n_own)) return rc;
-    return launch_well<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if (h->wide_blocks > 0) {
+    switch (DT) {
+      case RLH_S: return wide_spmm_s(h, part, m, X_, ldx, n_own, H_, ldh, Y_, ldy, B_, ldb, cy, cp, cb);
+      case RLH_D: return wide_spmm_d(h, part, m, X_, ldx, n_own, H_, ldh, Y_, ldy, B_, ldb, cy, cp, cb);
+      case RLH_C: return wide_spmm_c(h, part, m, X_, ldx, n_own, H_, ldh, Y_, ldy, B_, ldb, cy, cp, cb);
+      default:    return wide_spmm_z(h, part, m, X_, ldx, n_own, H_, ldh, Y_, ldy, B_, ldb, cy, cp, cb);
+    }
+  }
+  if constexpr (!DType<DT>::cplx) {
+    if (h->well_blocks > 0) {
+      if (part != 0)
+        if (int rc = well_split(h, n_own)) return rc;
+      return launch_well<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+    }
   }
   if (part == 1) return 0;                    // sliced layout: everything happens in part 2
-  static const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
+  const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
   if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if (m <= 16 || JTMAX == 16 || jt_cap <= 16) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
@@ -877,92 +798,6 @@ static int csr_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, 
 }
 
 
-// Launch order of the windowed layout's blocks.  Workgroup w of the persistent grid processes
-// sched[w], sched[w + grid], ...; workgroups w and w + 8 share an XCD and its L2 under the
-// observed round-robin placement, so the 32 positions {r * grid + 8 i + x, i < 32} are blocks that
-// XCD x works on at the same time.  A block's windows are mostly the own rows of other blocks
-// (the z planes of a 3-D stencil are the rows of the blocks ~n_y n_x / 1024 further on): the
-// schedule makes such blocks concurrent on one XCD, so that the window one of them stages is an
-// L2 hit left by the block that owns those rows, instead of a second and third trip over the fabric
-// (speed only: any order gives the same result).  Greedy: a group of 32 is grown from the lowest
-// unscheduled block by repeatedly adding the unscheduled block that overlaps most with the group.
-// position r * grid + 8 i + x  <-  member i of group g = 8 r + x of the ordered block list
-static void well_layout(const std::vector<int32_t> &order, int num_cu, std::vector<int32_t> &sched, int &grid) {
-  const int xcds = 8;
-  int per_xcd = num_cu / xcds;
-  if (per_xcd < 1) per_xcd = 1;
-  const int64_t nb = (int64_t)order.size();
-  if (nb <= (int64_t)xcds * per_xcd) {
-    grid = (int)nb;
-    sched = order;
-    return;
-  }
-  grid = xcds * per_xcd;
-  const int64_t ngroups = (nb + per_xcd - 1) / per_xcd;
-  const int64_t rounds = (ngroups + xcds - 1) / xcds;
-  sched.assign((size_t)(rounds * grid), -1);
-  for (int64_t k = 0; k < nb; ++k) {
-    const int64_t g = k / per_xcd, i = k % per_xcd;
-    sched[(size_t)((g / xcds) * grid + i * xcds + g % xcds)] = order[(size_t)k];
-  }
-}
-
-template <typename WinVec>
-static void well_schedule(const std::vector<WinVec> &wins, int64_t nblocks, int64_t n_rows, int num_cu,
-                          std::vector<int32_t> &order) {
-  const int xcds = 8;
-  int per_xcd = num_cu / xcds;
-  if (per_xcd < 1) per_xcd = 1;
-  order.clear();
-  order.reserve((size_t)nblocks);
-  if (nblocks <= xcds * per_xcd || env_int("RLH_SPMM_SCHED", 1) == 0) {
-    for (int64_t b = 0; b < nblocks; ++b) order.push_back((int32_t)b);
-    return;
-  }
-  // overlap graph: weight = rows of block c that block b stages (both directions)
-  std::vector<std::vector<std::pair<int32_t, int32_t>>> adj((size_t)nblocks);
-  for (int64_t b = 0; b < nblocks; ++b)
-    for (const auto &w : wins[b]) {
-      int64_t lo = w.start, hi = (int64_t)w.start + w.len;
-      if (hi > n_rows) hi = n_rows;                 // halo columns are not rows of this shard
-      for (int64_t c = lo / kWellRows; c * kWellRows < hi; ++c) {
-        if (c == b) continue;
-        const int64_t ov = std::min<int64_t>(hi, (c + 1) * kWellRows) - std::max<int64_t>(lo, c * kWellRows);
-        if (ov <= 0) continue;
-        adj[b].push_back({(int32_t)c, (int32_t)ov});
-        adj[c].push_back({(int32_t)b, (int32_t)ov});
-      }
-    }
-  std::vector<char> done((size_t)nblocks, 0);
-  std::vector<int64_t> weight((size_t)nblocks, 0);
-  int64_t seed = 0;
-  while ((int64_t)order.size() < nblocks) {
-    std::vector<int32_t> touched;
-    int members = 0;
-    auto add = [&](int32_t b) {
-      done[b] = 1;
-      order.push_back(b);
-      ++members;
-      for (const auto &e : adj[b])
-        if (!done[e.first]) {
-          if (weight[e.first] == 0) touched.push_back(e.first);
-          weight[e.first] += e.second;
-        }
-    };
-    while (members < per_xcd && (int64_t)order.size() < nblocks) {
-      int32_t best = -1;
-      for (int32_t c : touched)
-        if (!done[c] && (best < 0 || weight[c] > weight[best] || (weight[c] == weight[best] && c < best))) best = c;
-      if (best < 0) {
-        while (seed < nblocks && done[seed]) ++seed;
-        best = (int32_t)seed;
-      }
-      add(best);
-    }
-    for (int32_t c : touched) weight[c] = 0;
-  }
-}
-
 // The two launch orders of rlh_spmm_part for the own / halo boundary n_own: blocks that reference
 // only own columns, and the rest (each keeps the grouped order of the full schedule).
 static int well_split(rlh_csr *h, int64_t n_own) {
@@ -987,41 +822,18 @@ static int well_split(rlh_csr *h, int64_t n_own) {
   return 0;
 }
 
-// Host side of the windowed layout.  Returns 0 with h->well_blocks == 0 when the matrix does not
-// qualify (a row longer than 32 entries, a block whose windows do not fit the LDS buffer, or too
-// little column locality for the staging to pay: the sliced layout is built instead).
-template <typename F>
-static void parallel_blocks(int64_t nblocks, F fn) {
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt < 1) nt = 1;
-  if (nt > 16) nt = 16;
-  if ((int64_t)nt > nblocks) nt = (unsigned)(nblocks > 0 ? nblocks : 1);
-  std::atomic<int64_t> next(0);
-  auto worker = [&]() {
-    for (;;) {
-      const int64_t b0 = next.fetch_add(64);
-      if (b0 >= nblocks) break;
-      const int64_t b1 = b0 + 64 < nblocks ? b0 + 64 : nblocks;
-      for (int64_t b = b0; b < b1; ++b) fn(b);
-    }
-  };
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto &t : pool) t.join();
-}
-
+// Host side of the 1024-row windowed layout.  Returns 0 with h->well_blocks == 0 when the matrix
+// does not qualify (a row longer than 8 entries, a block whose windows do not fit the LDS buffer,
+// or too little column locality for the staging to pay).
 template <int DT>
 static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const void *values_, bool force) {
   using T = typename DType<DT>::T;
   constexpr int SMAX = WellCfg<T>::SMAX;
-  constexpr int kGap = 32;                       // columns: smaller holes between windows are bridged
   const T *values = (const T *)values_;
   const int64_t n = h->n_rows;
   const int64_t nblocks = (n + kWellRows - 1) / kWellRows;
   h->well_blocks = 0;
   if (nblocks == 0 || h->nnz == 0) return 0;
-  struct Win { int32_t start, len, off; };      // off: position of the window in the staged image
   std::vector<std::vector<Win>> wins((size_t)nblocks);
   std::vector<int32_t> width((size_t)nblocks, 0), ngroups((size_t)nblocks, 0);
   parallel_blocks(nblocks, [&](int64_t b) {
@@ -1029,48 +841,8 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     int64_t w = 0;
     for (int64_t r = r0; r < r1; ++r) w = std::max<int64_t>(w, indptr[r + 1] - indptr[r]);
     width[b] = (int32_t)std::min<int64_t>(w, 1 << 20);
-    std::vector<int32_t> cols(indices + indptr[r0], indices + indptr[r1]);
-    std::sort(cols.begin(), cols.end());
-    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    std::vector<Win> &ws = wins[b];
-    const int64_t nc = h->n_cols;
-    // 16-byte staging loads: a window starts on a multiple of 8 columns (a piece is 2 to 8
-    // elements and must not lie across the own / halo boundary of a row shard), and every 64-column group
-    // stays inside the column range where the matrix is wide enough (a window at the far end is
-    // moved left instead of being padded past the last column)
-    auto place = [&](int64_t first, int64_t last, int64_t &start, int64_t &padded) {
-      start = first & ~(int64_t)7;
-      padded = (last - start + 1 + 63) / 64 * 64;
-      if (start + padded > nc && nc >= padded) start = nc - padded;
-    };
-    for (size_t i = 0; i < cols.size();) {
-      size_t k = i;
-      while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= kGap) ++k;
-      int64_t first = cols[i], last = cols[k], start, padded;
-      for (;;) {
-        place(first, last, start, padded);
-        if (ws.empty() || start >= (int64_t)ws.back().start + ws.back().len) break;
-        first = ws.back().start;               // moved onto its predecessor: one window for both
-        ws.pop_back();
-      }
-      ws.push_back(Win{(int32_t)start, (int32_t)(last - start + 1), 0});
-      if (ws.size() > 4096) break;               // hopeless: stop counting
-      i = k + 1;
-    }
-    int32_t off = 0;
-    for (Win &w : ws) {
-      w.off = off;
-      off += (w.len + 63) / 64 * 64;
-      if (off > (1 << 24)) break;
-    }
-    if (ws.empty()) {                            // a block of empty rows still stages one group
-      ws.push_back(Win{0, 1, 0});
-      off = 64;
-    }
-    off = (off + 511) / 512 * 512;               // groups per block: a multiple of 8 (one 16-byte load
-                                                 // covers 2, 4 or -- bfloat16 -- 8 groups); the extra ones
-                                                 // repeat the last
-    ngroups[b] = off / 64;
+    // groups per block: a multiple of 8 (one 16-byte load covers 2, 4 or -- bfloat16 -- 8 groups)
+    ngroups[b] = find_windows(indptr, indices, r0, r1, h->n_cols, 32, 8, wins[b]) / 64;
   });
   int32_t wmax = 0, gmax = 0;
   int64_t staged = 0, slots = 0;
@@ -1081,12 +853,12 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     slots += (int64_t)width[b] * kWellRows;
   }
   h->well_ratio = slots > 0 ? (double)staged / (double)slots : 0.0;
-  if (wmax > (sizeof(T) <= 8 ? 32 : 16) || gmax > 16 * SMAX) return 0;
+  if (wmax > 8 || gmax > 16 * SMAX) return 0;
   // measured (profiles/r01_spmm_windowed.txt): at 0.65 staged elements per entry slot (5-point
   // stencil) the windowed kernel is 1.27x faster than the sliced one, at 1.06 (a diagonal
   // matrix) 4 % slower
   if (!force && staged * 10 > slots * 9) return 0;
-  h->well_wmax = wmax <= 8 ? 8 : (wmax <= 16 ? 16 : 32);
+  h->well_wmax = 8;
   std::vector<WellMeta> meta((size_t)nblocks);
   int64_t eoff = 0;
   int64_t goff = 0;
@@ -1097,34 +869,27 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   }
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
   std::vector<int32_t> gsrc((size_t)goff);
-  const int64_t epad = 32;                       // the kernel reads WMAX slots whatever the block's width
+  const int64_t epad = 8;                        // the kernel reads 8 slots whatever the block's width
   std::vector<uint16_t> idx((size_t)(eoff + epad) * kWellRows, 0);
   std::vector<T> vals((size_t)(eoff + epad) * kWellRows);
   memset(vals.data() + (size_t)eoff * kWellRows, 0, (size_t)epad * kWellRows * sizeof(T));
   parallel_blocks(nblocks, [&](int64_t b) {
     const std::vector<Win> &ws = wins[b];
-    int32_t filled = 0, last = 0;
-    for (const Win &w : ws)
-      for (int32_t g = 0; g < (w.len + 63) / 64; ++g, ++filled) gsrc[meta[b].goff + w.off / 64 + g] = last = w.start + 64 * g;
-    for (; filled < ngroups[b]; ++filled) gsrc[meta[b].goff + filled] = last;
+    fill_group_sources(ws, ngroups[b], gsrc.data() + meta[b].goff);
     const int64_t r0 = b * kWellRows;
     for (int l = 0; l < kWellRows; ++l) {
       const int64_t r = r0 + l;
       const int64_t p = r < n ? indptr[r] : 0, len = r < n ? indptr[r + 1] - p : 0;
+      // padding slots carry value 0 and the position of the row's own first entry, so that they
+      // only ever touch a column the row references (0 * Inf of a foreign column would be NaN)
+      const uint16_t padpos = len > 0 ? (uint16_t)staged_position(ws, indices[p]) : 0;
       for (int32_t t = 0; t < (width[b] + 7) / 8 * 8; ++t) {
         const int64_t ev = well_val_index<T>(meta[b].eoff, t, l), ei = well_idx_index(meta[b].eoff, t, l);
         if (t < len) {
-          const int32_t c = indices[p + t];
-          // last window starting at or before c
-          size_t lo = 0, hi = ws.size();
-          while (hi - lo > 1) {
-            const size_t mid = (lo + hi) / 2;
-            if (ws[mid].start <= c) lo = mid; else hi = mid;
-          }
-          idx[ei] = (uint16_t)(ws[lo].off + (c - ws[lo].start));
+          idx[ei] = (uint16_t)staged_position(ws, indices[p + t]);
           vals[ev] = values[p + t];
         } else {
-          idx[ei] = 0;
+          idx[ei] = padpos;
           memset(&vals[ev], 0, sizeof(T));
         }
       }
@@ -1138,7 +903,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     if (gsrc[g] & 7) h->well_aligned = 0;
   }
   std::vector<int32_t> sched;
-  well_schedule(wins, nblocks, n, ctx().num_cu, h->well_order);
+  well_schedule(wins, nblocks, n, kWellRows, ctx().num_cu, h->well_order);
   well_layout(h->well_order, ctx().num_cu, sched, h->well_grid);
   h->well_maxcol.resize((size_t)nblocks);
   for (int64_t b = 0; b < nblocks; ++b) h->well_maxcol[(size_t)b] = wins[b].back().start + wins[b].back().len - 1;
@@ -1189,20 +954,25 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->well_ratio = 0.0; h->well_sched = nullptr; h->well_sched_len = 0; h->well_grid = 0; h->well_inbounds = 0; h->well_aligned = 0;
   h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
   h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
-  // layout: the windowed one when the matrix qualifies, else the sliced one
-  // (RLH_SPMM_FORMAT=sell|well overrides the locality test; read per handle so tests can cover both)
+  h->wide_blocks = 0; h->wide_meta = nullptr; h->wide_gsrc = nullptr; h->wide_idx = nullptr; h->wide_vals = nullptr;
+  h->wide_gmax = 0; h->n_slices = 0; h->padded = 0; h->device_bytes = 0; h->well_wmax = 0;
+  // Layout (RLH_SPMM_FORMAT=sell|well|wide overrides the choice and the locality test; read per
+  // handle so tests can cover all three): rows of at most 8 entries of a real type -> the 1024-row
+  // windowed layout; otherwise, or when that one does not qualify -> the 256-row interleaved
+  // layout; no column locality at all -> sliced ELL.
   const char *fmt = getenv("RLH_SPMM_FORMAT");
   const bool want_sell = fmt && !strcmp(fmt, "sell"), force_well = fmt && !strcmp(fmt, "well");
+  const bool force_wide = fmt && !strcmp(fmt, "wide");
   int rc = 0;
-  if (!want_sell) {
+  if (!want_sell && !force_wide) {
     switch (dtype) {
       case RLH_S: rc = well_build<RLH_S>(h, indptr, indices, values, force_well); break;
       case RLH_D: rc = well_build<RLH_D>(h, indptr, indices, values, force_well); break;
-      case RLH_C: rc = well_build<RLH_C>(h, indptr, indices, values, force_well); break;
-      case RLH_Z: rc = well_build<RLH_Z>(h, indptr, indices, values, force_well); break;
+      default: break;
     }
   }
-  if (rc == 0 && h->well_blocks == 0) {
+  if (rc == 0 && h->well_blocks == 0 && !want_sell) rc = wide_build(h, indptr, indices, values, force_well || force_wide);
+  if (rc == 0 && h->well_blocks == 0 && h->wide_blocks == 0) {
     switch (dtype) {
       case RLH_S: rc = csr_build<RLH_S>(h, indptr, indices, values); break;
       case RLH_D: rc = csr_build<RLH_D>(h, indptr, indices, values); break;
@@ -1229,6 +999,7 @@ int rlh_csr_destroy(rlh_csr_t h) {
     if (h->well_sched) (void)hipFree(h->well_sched);
     for (int k = 0; k < 2; ++k)
       if (h->well_sched_part[k]) (void)hipFree(h->well_sched_part[k]);
+    wide_destroy(h);
   }
   delete h;
   return 0;
@@ -1245,7 +1016,7 @@ int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, in
 
 int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per_slot) {
   RLH_REQUIRE(h != nullptr, "rlh_csr_layout: null handle");
-  if (layout) *layout = h->well_blocks > 0 ? 1 : 0;
+  if (layout) *layout = h->wide_blocks > 0 ? 2 : (h->well_blocks > 0 ? 1 : 0);
   if (stored) *stored = h->padded;
   if (staged_per_slot) *staged_per_slot = h->well_ratio;
   return 0;
@@ -1314,8 +1085,8 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
   RLH_REQUIRE(m >= 0, "rlh_spmm_cheb_bf16: negative block size");
   if (m == 0 || h->n_rows == 0) return 0;
   RLH_REQUIRE(h->dtype == RLH_S && h->well_blocks > 0 && h->well_inbounds,
-              "rlh_spmm_cheb_bf16: needs a float32 operator in the windowed layout with every staging group inside "
-              "the column range");
+              "rlh_spmm_cheb_bf16: needs a float32 operator in the 1024-row windowed layout (rows of at most 8 "
+              "entries) with every staging group inside the column range");
   RLH_REQUIRE(h->n_rows <= n_own && n_own <= h->n_cols, "rlh_spmm_cheb_bf16: the operator block must be square in its own rows");
   RLH_REQUIRE(n_own == h->n_cols || (H16 && h->well_aligned && n_own % 8 == 0 && ldh % 8 == 0 && ((uintptr_t)H16 % 16) == 0),
               "rlh_spmm_cheb_bf16: a halo block needs n_own and ldh to be multiples of 8, a 16-byte aligned block "
@@ -1338,9 +1109,7 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
   hipLaunchKernelGGL((well_cheb_bf16_kernel<W>), dim3((unsigned)nb), dim3(1024), 0, c.stream, h->well_meta,       \
                      h->well_gsrc, h->well_idx, (const float *)h->well_vals, h->n_rows, sched, sched_len, Y, ldy, \
                      n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp, (float)cb)
-  if (h->well_wmax <= 8) RLH_BF_LAUNCH(8);
-  else if (h->well_wmax <= 16) RLH_BF_LAUNCH(16);
-  else RLH_BF_LAUNCH(32);
+  RLH_BF_LAUNCH(8);
 #undef RLH_BF_LAUNCH
   RLH_HIP(hipGetLastError());
   return 0;

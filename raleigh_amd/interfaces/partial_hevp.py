@@ -80,7 +80,12 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
             if verb > -1:
                 print('estimated factorization error: %.1e' % err)
                 print('setup time: %.2e' % (time.time() - start))
-        neg, pos = solver.inertia()
+        try:
+            neg, pos = solver.inertia()
+        except RuntimeError as err:
+            if verb > -1:
+                print('%s' % err)
+            return None, None, -1
         if verb > -1:
             print('positive eigenvalues: %d' % pos)
             print('negative eigenvalues: %d' % neg)

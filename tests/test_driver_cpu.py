@@ -208,6 +208,31 @@ def test_complex_hermitian_shift_invert_config5_shape():
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
 
 
+def test_inertia_refuses_unsymmetric_pivoting():
+    """An indefinite matrix with a zero diagonal entry makes SuperLU interchange rows even with
+    diag_pivot_thresh = 0: diag(U) then has the wrong signs, so the solver must refuse to report an
+    inertia (and partial_hevp must return status -1) instead of silently mapping `which` wrongly."""
+    import scipy.sparse as sp
+    from raleigh_amd.algebra.hip.host_ops import SparseSymmetricSolver
+    from raleigh_amd.interfaces import partial_hevp
+    n = 40
+    d = np.linspace(1.0, 3.0, n)
+    d[0] = 0.0                      # zero pivot in the first elimination step
+    A = sp.diags([np.ones(n - 1), d, np.ones(n - 1)], [-1, 0, 1], format='csr')
+    solver = SparseSymmetricSolver()
+    solver.analyse(A, 0.0)
+    solver.factorize()
+    with pytest.raises(RuntimeError):
+        solver.inertia()
+    lmd, x, status = partial_hevp(A, sigma=0.0, which=3, verb=-1)
+    assert status == -1 and lmd is None
+    # a definite shift of the same matrix factorises symmetrically and counts correctly
+    solver.analyse(A, -1.0)
+    solver.factorize()
+    assert solver.inertia() == (int(np.sum(np.linalg.eigvalsh(A.toarray()) < -1.0)),
+                                n - int(np.sum(np.linalg.eigvalsh(A.toarray()) < -1.0)))
+
+
 def test_device_chebyshev_preconditioner():
     """Polynomial preconditioner built from the operator itself: same eigenvalues, far fewer iterations."""
     from raleigh_amd.interfaces import partial_hevp

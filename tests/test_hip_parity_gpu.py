@@ -319,14 +319,22 @@ def test_convert_precision(src, dst):
     assert np.all(y[:4] == np.arange(1, 5)[:, None]) and np.all(y[9:] == np.arange(10, m + 3)[:, None])
 
 
-# ---------------------------------------------------------------- both device layouts of the sparse operator
-@pytest.fixture(params=['sell', 'well'])
+# ---------------------------------------------------------------- the three device layouts of the sparse operator
+@pytest.fixture(params=['sell', 'well', 'wide'])
 def spmm_format(request, monkeypatch):
     """RLH_SPMM_FORMAT is read by rlh_csr_create per handle: 'sell' = sliced ELL (per-entry
-    gathers), 'well' = windowed ELL (column windows staged through the LDS) even where the
-    locality test would not choose it; a matrix the windowed layout cannot hold falls back."""
+    gathers), 'well' = 1024-row windowed ELL (column windows staged through the LDS, rows of at
+    most 8 entries of a real type) even where the locality test would not choose it, 'wide' = the
+    256-row interleaved windowed layout (any row length, any type); a matrix 'well' cannot hold
+    falls to 'wide'."""
     monkeypatch.setenv('RLH_SPMM_FORMAT', request.param)
     return request.param
+
+
+def expected_layout(fmt, key, max_row=7):
+    if fmt == 'well' and (key in 'cz' or max_row > 8):
+        return 'wide'
+    return fmt
 
 
 def _sym(A, key):
@@ -425,7 +433,7 @@ def test_spmm_layouts_halo_block(spmm_format, key, rows):
     x = rnd((m, n), key, rng)
     X, Hb = Vectors(np.ascontiguousarray(x[:, r0:r1])), Vectors(np.ascontiguousarray(x[:, halo]))
     Y = Vectors(r1 - r0, m, data_type=DT[key])
-    assert op.layout()[0] == spmm_format
+    assert op.layout()[0] == expected_layout(spmm_format, key)
     op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hb.data_ptr(), Hb.ld())
     ref = (A @ x.T).T[:, r0:r1]
     tol = 2e-6 if key == 'c' else 1e-13
@@ -453,9 +461,9 @@ def test_fused_chebyshev_step_layouts(spmm_format, key):
 
 
 def test_layout_choice(monkeypatch):
-    """The locality test: the stencil gets the windowed layout, a random pattern and a matrix
-    with a long row the sliced one; the environment override wins where the layout can hold
-    the matrix."""
+    """The layout choice: the stencil gets the 1024-row windowed layout, a matrix with a long row
+    the interleaved one, a random pattern the sliced one; the environment override wins where the
+    layout can hold the matrix."""
     from raleigh_amd.algebra.hip import CsrOperator
     monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
     A = lap3d(23, 19, 17, 1.0, 1.01, 1.02)
@@ -469,12 +477,16 @@ def test_layout_choice(monkeypatch):
     assert lay == 'sell' and ratio > 0.9
     D = sp.lil_matrix(A)
     D[5, :40] = 1.0
-    assert CsrOperator(sp.csr_matrix(D)).layout()[0] == 'sell'
+    assert CsrOperator(sp.csr_matrix(D)).layout()[0] == 'wide'        # a 40-entry row: interleaved layout
+    assert CsrOperator(A.astype(np.complex128)).layout()[0] == 'wide'  # complex operators too
     monkeypatch.setenv('RLH_SPMM_FORMAT', 'sell')
     assert CsrOperator(A).layout()[0] == 'sell'
     monkeypatch.setenv('RLH_SPMM_FORMAT', 'well')
-    assert CsrOperator(sp.csr_matrix(D)).layout()[0] == 'sell'        # a 40-entry row does not fit
+    assert CsrOperator(sp.csr_matrix(D)).layout()[0] == 'wide'        # a 40-entry row does not fit 'well'
     assert CsrOperator(A.astype(np.float32)).layout()[0] == 'well'
+    monkeypatch.setenv('RLH_SPMM_FORMAT', 'wide')
+    lay, stored, ratio = CsrOperator(A).layout()
+    assert lay == 'wide' and stored == 30 * 256 * 8                   # 30 blocks of 256 rows, one chunk of 8 slots
 
 
 def test_spmm_windowed_schedule_many_blocks(monkeypatch):
@@ -557,7 +569,7 @@ def test_spmm_interior_boundary_parts(spmm_format, key):
     y1 = Y.data()
     done = y1[0] != 777                                   # rows written by part 1
     assert np.all(np.isfinite(y1[:, done])) and cases.rel(y1[:, done], ref[:, done]) < tol
-    if spmm_format == 'well':
+    if spmm_format in ('well', 'wide'):
         assert 0.5 < done.mean() < 1.0                    # most blocks are interior, the shard ends are not
     else:
         assert not done.any()                             # sliced layout: everything is left to part 2
@@ -696,9 +708,9 @@ def test_full_size_roofline_point_fp64():
 @pytest.mark.parametrize('key', ['d', 's'])
 def test_spmm_layouts_agree_on_a_large_irregular_matrix(monkeypatch, key):
     """n = 3*10^5 rows, 1..27 entries per row (banded couplings of varying reach plus a few far
-    ones, empty rows): several hundred 1024-row blocks through the XCD-aware schedule, all three
-    register-slot variants of the windowed kernel -- against the sliced kernel, which does one
-    gather per entry and shares nothing with it beyond the CSR input."""
+    ones, empty rows): more than a thousand 256-row blocks of the interleaved layout through the
+    XCD-aware schedule, one to four entry chunks per row -- against the sliced kernel, which does
+    one gather per entry and shares nothing with it beyond the CSR input."""
     from raleigh_amd.algebra.hip import Vectors, CsrOperator
     rng = np.random.default_rng(77)
     n = 300007
@@ -718,17 +730,17 @@ def test_spmm_layouts_agree_on_a_large_irregular_matrix(monkeypatch, key):
     x = rnd((m, n), key, rng)
     X = Vectors(x)
     out = {}
-    for fmt in ('sell', 'well'):
+    for fmt in ('sell', 'wide'):
         monkeypatch.setenv('RLH_SPMM_FORMAT', fmt)
         op = CsrOperator(A)
         assert op.layout()[0] == fmt
         Y = Vectors(n, m, data_type=DT[key])
         op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
         out[fmt] = Y.data()
-    assert cases.rel(out['well'], out['sell']) < (2e-6 if key == 's' else 1e-14)
+    assert cases.rel(out['wide'], out['sell']) < (2e-6 if key == 's' else 1e-14)
     i = rng.integers(0, n, 200)                                                 # and a sample of rows against SciPy
     ref = (A[i] @ x.T).T
-    assert cases.rel(out['well'][:, i], ref) < (2e-6 if key == 's' else 1e-13)
+    assert cases.rel(out['wide'][:, i], ref) < (2e-6 if key == 's' else 1e-13)
 
 
 def test_new_entry_points_reject_bad_arguments(monkeypatch):
@@ -803,3 +815,74 @@ def test_fused_chebyshev_step_bf16_row_shard(rows):
     got = out.data()[:, :nown]
     assert np.all(np.isfinite(got))
     assert np.all(np.abs(got - exact) <= 2.0 ** -8 * np.abs(exact) + 1e-6)
+
+
+# ---------------------------------------------------------------- interleaved layout: wide rows, every type
+@pytest.mark.parametrize('key', KEYS)
+@pytest.mark.parametrize('m,nv', [(1, 0), (5, 0), (16, 0), (33, 0), (16, 8), (40, 32), (7, 16), (9, 4)])
+def test_spmm_wide_rows_fe_like(monkeypatch, key, m, nv):
+    """FE-like operator (58 entries per interior row: 8 entry chunks, three column windows per block)
+    through the interleaved layout, plain and fused Chebyshev forms, every vectors-per-pass variant
+    (RLH_WIDE_NV forces one where the type has it), block sizes that leave a short last pass."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import fe_surrogate
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    if nv:
+        monkeypatch.setenv('RLH_WIDE_NV', str(nv))
+    A = _sym(fe_surrogate(grid=(9, 11, 13), dof=2), key)
+    n = A.shape[0]
+    assert np.diff(A.indptr).max() == 58
+    op = CsrOperator(A)
+    assert op.layout()[0] == 'wide'
+    rng = np.random.default_rng(m + nv)
+    x = rnd((m, n), key, rng)
+    X, Y = Vectors(x), Vectors(n, m, data_type=DT[key])
+    Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+    ref = (A @ x.T).T
+    tol = 3e-6 if key in 'sc' else 1e-13
+    assert cases.rel(Y.data(), ref) < tol
+    p0, b0 = rnd((m, n), key, rng), rnd((m, n), key, rng)
+    P, B = Vectors(p0.copy()), Vectors(b0.copy())
+    op.cheb_step_ptr(m, X, P, B, 1.3, -0.3, -0.7)
+    assert cases.rel(P.data(), 1.3 * x - 0.3 * p0 - 0.7 * (b0 - ref)) < tol
+    assert np.array_equal(X.data(), x)
+
+
+def test_spmm_wide_padding_never_touches_foreign_columns(monkeypatch):
+    """A non-finite entry of x in a column a row does not reference must not reach that row
+    (padding slots point at the row's own first entry): the reference CSR product only touches
+    referenced columns (mkl_wrap.py:246-276)."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    for fmt in ('well', 'wide'):
+        monkeypatch.setenv('RLH_SPMM_FORMAT', fmt)
+        n = 3000
+        A = sp.diags([np.ones(n - 1), 2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format='lil')
+        A[10, 10:14] = 1.0
+        A[10:14, 10] = 1.0
+        A = sp.csr_matrix(A)                    # rows of 2 .. 5 entries: every block has padding slots
+        x = np.ones((2, n))
+        x[:, 0] = np.inf                        # column 0 is referenced by rows 0 and 1 only
+        op = CsrOperator(A)
+        X, Y = Vectors(x), Vectors(n, 2)
+        op.apply_ptr(2, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+        y = Y.data()
+        assert not np.any(np.isfinite(y[:, :2])) and np.all(np.isfinite(y[:, 2:]))
+        assert np.allclose(y[:, 2:], (A @ np.ones(n))[2:])
+
+
+def test_config3_surrogate_apply_full_size():
+    """BASELINE config 3 stand-in (FE-like surrogate for shipsec5, n = 179 860, ~55
+    entries per row): the operator application on the full matrix against the oracle, m = 16 (the
+    block size of `which = 10`)."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from raleigh_amd.synthetic import fe_surrogate
+    A = fe_surrogate()
+    n = A.shape[0]
+    assert n == 179860 and 54 < A.nnz / n < 57
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((16, n))
+    op = SparseSymmetricMatrix(A)
+    X, Y = Vectors(x), Vectors(n, 16)
+    op.apply(X, Y)
+    assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < 1e-13

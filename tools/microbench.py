@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--lap2d', type=int, default=0, help='2-D Laplacian side (n = N^2), SpMM line only')
     ap.add_argument('--band', type=int, default=-1, help='banded test matrix with diagonals -band..band (needs --n)')
+    ap.add_argument('--fe', action='store_true', help='SpMM on the FE-like shipsec5 surrogate (BASELINE config 3; n = 179860)')
+    ap.add_argument('--herm', type=int, default=0, help='SpMM on the Hermitian lap3d + i skew operator of side N (config 5; use --dtype z)')
     args = ap.parse_args()
     from raleigh_amd import _lib
     from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
@@ -32,6 +34,10 @@ def main():
         n = args.lap ** 3
     if args.lap2d:
         n = args.lap2d ** 2
+    if args.fe:
+        n = 179860
+    if args.herm:
+        n = args.herm ** 3
     code = _lib.dtype_code(dt)
     X, Y, W = Vectors(n, m, data_type=dt), Vectors(n, m, data_type=dt), Vectors(n, m, data_type=dt)
     # device-side fill: upload one random column block and replicate (host RNG for 10^7 x 32 is slow)
@@ -88,6 +94,28 @@ def main():
         nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
         med, mn = timed(lambda: op.apply(X, W))
         print('%-18s %8.3f ms (min %8.3f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % ('spmm band %d' % args.band, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
+    if args.fe or args.herm:
+        from raleigh_amd.synthetic import fe_surrogate, hermitian_lap3d_rows
+        from raleigh_amd.algebra.hip import CsrOperator
+        t0 = time.time()
+        if args.fe:
+            A = fe_surrogate().astype(dt)
+        else:
+            A = hermitian_lap3d_rows(args.herm, args.herm, args.herm, 1.0, 1.01, 1.02, 0, n).astype(dt)
+        op = CsrOperator(A)
+        print('%s setup %.1f s, nnz=%d (%.1f per row), layout %s' % ('fe surrogate' if args.fe else 'hermitian lap3d',
+              time.time() - t0, A.nnz, A.nnz / n, op.layout()))
+        nbytes = A.nnz * (es + 4) + (n + 1) * 4 + 2 * B
+        fn = lambda: op.apply_ptr(m, X.data_ptr(), X.ld(), W.data_ptr(), W.ld())
+        med, mn = timed(fn, reps=max(args.reps, 30))
+        print('%-18s %8.4f ms (min %8.4f)  %8.1f GB/s  %5.1f%% of 8 TB/s' % ('spmm ' + ('fe' if args.fe else 'herm'), med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80))
+        # back-to-back launches (one event pair around 20 applications): what a solver sees
+        fn(); _lib.check(L.rlh_sync())
+        _lib.check(L.rlh_timer_start())
+        for _ in range(20):
+            fn()
+        _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
+        print('%-18s %8.4f ms per application, 20 back to back  %8.1f GB/s' % ('', ms.value / 20, nbytes / (ms.value / 20) / 1e6))
     if args.lap or args.lap2d:
         from oracle.sparse import lap3d
         t0 = time.time()
