@@ -83,6 +83,16 @@ int rlh_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch,
 int rlh_gram(int dtype, int64_t n, int64_t mx, const void *X, int64_t ldx,
              int64_t my, const void *Y, int64_t ldy, void *d_out, void *h_out);
 
+/* Gram of two CONCATENATED windows in one pass (the solver's back-to-back Gram
+ * pairs share an operand -- solver.py:854-861 XAX + XBX, :1321-1339 ZAY + ZBY, :1376-1381
+ * XBY + YBY, :1444-1447 XAY + YAY): out = [Y_0 | ... | Y_{ny-1}]^H [X_0 | ... | X_{nx-1}], shape
+ * (sum my, sum mx), C order; up to 4 blocks per window, every block is read once.  X, ldx, mx,
+ * Y, ldy, my: HOST arrays of nx / ny device pointers, leading dimensions and column counts.
+ * d_out / h_out as rlh_gram. */
+int rlh_gram_multi(int dtype, int64_t n, int nx, const void *const *X, const int64_t *ldx,
+                   const int64_t *mx, int ny, const void *const *Y, const int64_t *ldy,
+                   const int64_t *my, void *d_out, void *h_out);
+
 /* ---- K2: column-wise dots (dense_numpy.py:68-76; dense_cublas.py:233-243)
  * out[i] = sum_r conj(Y[r,i]) * X[r,i], i < m. */
 int rlh_dots(int dtype, int64_t n, int64_t m, const void *X, int64_t ldx,
@@ -231,6 +241,37 @@ int rlh_gather_rows_bf16(int64_t nidx, const int64_t *d_idx, int64_t m, const vo
  * idx: DEVICE int64 (built once per operator). */
 int rlh_gather_rows(int dtype, int64_t nidx, const int64_t *d_idx, int64_t m,
                     const void *X, int64_t ldx, void *Out, int64_t ldo);
+
+/* ---- incomplete LU preconditioner on the device
+ *      (sparse_mkl.py:122-140 IncompleteLU -> mkl_wrap.py:279-347: mkl dcsrilut once, then two
+ *      mkl_dcsrtrsv per VECTOR on the host)
+ * rlh_ilut_factor: dual-threshold ILUT(p = maxfil, tau = tol) of the FULL matrix given as 0-based
+ * CSR in HOST memory (dtype RLH_D or RLH_Z); runs on the host (no GPU needed): entries below
+ * tol * ||row||_2 are dropped, at most maxfil entries are kept in the L part and in the U part of
+ * every row (mkl_wrap.py:305-331: tol, max_fill_rel * nnz / n).  The factors are read back as CSR
+ * with rlh_factors_get: which = 0 -> L strictly lower (unit diagonal implied), 1 -> U upper
+ * including the diagonal (diagonal first in every row, then ascending columns). */
+typedef struct rlh_factors *rlh_factors_t;
+int rlh_ilut_factor(rlh_factors_t *f, int dtype, int64_t n, const int64_t *indptr,
+                    const int32_t *indices, const void *values, double tol, int64_t maxfil);
+int rlh_factors_nnz(rlh_factors_t f, int64_t *nnz_l, int64_t *nnz_u);
+int rlh_factors_get(rlh_factors_t f, int which, int64_t *indptr, int32_t *indices, void *values);
+int rlh_factors_destroy(rlh_factors_t f);
+/* Sparse triangular operator for blocks of vectors (mkl_wrap.py:333-347 mkl_dcsrtrsv 'L','N','U'
+ * and 'U','N','N').  The triangular factor is given as 0-based CSR in HOST memory (the diagonal
+ * stored unless unit_diag); rows are grouped into dependency levels at creation.
+ * rlh_sptrsv_solve_chain: X = op[nops-1]^-1 ... op[0]^-1 B for column-major n x m blocks (B may be
+ * X); d_perm_in / d_perm_out: DEVICE int64 arrays or NULL -- row r of the internal scratch is row
+ * d_perm_in[r] of B, and is written to row d_perm_out[r] of X (row / column permutations of a
+ * factorisation P_r A P_c = L U).  Asynchronous on the library stream. */
+typedef struct rlh_sptrsv *rlh_sptrsv_t;
+int rlh_sptrsv_create(rlh_sptrsv_t *t, int dtype, int64_t n, const int64_t *indptr,
+                      const int32_t *indices, const void *values, int lower, int unit_diag);
+int rlh_sptrsv_info(rlh_sptrsv_t t, int64_t *nnz, int64_t *levels, int64_t *device_bytes);
+int rlh_sptrsv_solve_chain(int nops, const rlh_sptrsv_t *ops, const int64_t *d_perm_in,
+                           const int64_t *d_perm_out, int64_t m, const void *B, int64_t ldb,
+                           void *X, int64_t ldx);
+int rlh_sptrsv_destroy(rlh_sptrsv_t t);
 
 /* ---- K12: dense operator (dense_numpy.py:153-175; dense_cublas.py:732-776)
  * A: DEVICE, M x N, row-major (order 0, numpy C_CONTIGUOUS, lda >= N) or

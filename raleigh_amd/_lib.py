@@ -42,6 +42,7 @@ SIGNATURES = {
     'rlh_fetch': [_p, _p, _i64],
     'rlh_copy2d': [_p, _i64, _p, _i64, _i64, _i64, _int],
     'rlh_gram': [_int, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _p],
+    'rlh_gram_multi': [_int, _i64, _int, _p, _p, _p, _int, _p, _p, _p, _p, _p],
     'rlh_dots': [_int, _i64, _i64, _p, _i64, _p, _i64, _p, _p],
     'rlh_absmax': [_int, _i64, _i64, _p, _i64, ctypes.POINTER(ctypes.c_double)],
     'rlh_dots_transp': [_int, _i64, _i64, _p, _i64, _p, _i64, _p],
@@ -77,6 +78,14 @@ SIGNATURES = {
     'rlh_spmm_cheb_bf16_part': [_p, _int, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double,
                                 ctypes.c_double, ctypes.c_double],
     'rlh_gather_rows_bf16': [_i64, _p, _i64, _p, _i64, _p, _i64],
+    'rlh_ilut_factor': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, ctypes.c_double, _i64],
+    'rlh_factors_nnz': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    'rlh_factors_get': [_p, _int, _p, _p, _p],
+    'rlh_factors_destroy': [_p],
+    'rlh_sptrsv_create': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, _int, _int],
+    'rlh_sptrsv_info': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    'rlh_sptrsv_solve_chain': [_int, _p, _p, _p, _i64, _p, _i64, _p, _i64],
+    'rlh_sptrsv_destroy': [_p],
     'rlh_dense_apply': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64],
     'rlh_timer_start': [],
     'rlh_timer_stop': [ctypes.POINTER(ctypes.c_float)],

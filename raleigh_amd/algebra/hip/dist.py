@@ -20,7 +20,7 @@ import numpy as np
 import scipy.sparse as scs
 
 from ... import _lib
-from .vectors import Vectors
+from .vectors import Vectors, ReductionBatch
 from .memory import upload, download
 from .sparse import CsrOperator, full_from_upper
 
@@ -31,9 +31,15 @@ _REAL = {np.float32: np.float32, np.float64: np.float64,
 class Comm:
     """Process group + communication buffers of one rank."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_collectives=None):
+        import os
         import torch
         import torch.distributed as dist
+        # RLH_FORCE_COLLECTIVES=1 (or force_collectives=True): issue the all-reduce and the halo
+        # send / receive even with ONE rank (a rank then exchanges with itself), so that the RCCL calls
+        # and their ordering with the kernels' stream run on a single GPU
+        self.force = bool(int(os.environ.get('RLH_FORCE_COLLECTIVES', '0'))) if force_collectives is None \
+            else bool(force_collectives)
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.torch, self.dist, self.group = torch, dist, group
@@ -81,7 +87,7 @@ class Comm:
             if len(self._views) > 256:
                 self._views.clear()
             self._views[key] = view
-        if self.size > 1:
+        if self.size > 1 or self.force:
             self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
         out = np.empty((count,), dtype=np_dtype)
         if self.on_device:      # pinned staging + one stream synchronisation inside the library
@@ -203,6 +209,9 @@ class ShardedVectors(Vectors):
             out[:, r0:r1] = arr[:, :r1 - r0]
         return out[0] if i is not None else out
 
+    def reduction_batch(self):
+        return ShardedReductionBatch(self)
+
     # ---- reductions: local partial + one all-reduce
     def dot(self, other):
         m, k = self.nvec(), other.nvec()
@@ -226,6 +235,17 @@ class ShardedVectors(Vectors):
         _lib.check(_lib.lib().rlh_dots(self._code, self._vdim, m, self._ptr(), self._ld,
                                        other._ptr(), other._ld, buf.data_ptr(), None))
         return c.allreduce_from_device(buf, self.data_type(), m).copy()
+
+
+class ShardedReductionBatch(ReductionBatch):
+    """Local partial results side by side in the communication buffer, ONE all-reduce, one fetch."""
+
+    def _buffer(self, nbytes):
+        self._buf = self._proto._comm.reduction_buffer(nbytes)
+        return self._buf.data_ptr()
+
+    def _collect(self, ptr, count):
+        return self._proto._comm.allreduce_from_device(self._buf, self._proto.data_type(), count)
 
 
 class ShardedSparseMatrix:
@@ -264,6 +284,10 @@ class ShardedSparseMatrix:
         loc.sort_indices()
         cols = loc.indices.astype(np.int64)
         own = (cols >= r0) & (cols < r1)
+        if comm.size == 1 and comm.force:
+            # one rank exchanging with itself: the second half of the own rows is also fetched through
+            # the halo path (pack -> send to self -> receive -> halo block), so the whole exchange runs
+            own = cols < r0 + (r1 - r0) // 2
         halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
         owner = np.searchsorted(off, halo_cols, side='right') - 1
         # local column numbering: own rows first, then the halo rows from a multiple of 8 on (the
@@ -293,7 +317,7 @@ class ShardedSparseMatrix:
         comm.dist.all_gather_object(wants, mine, group=comm.group)
         self._send = []                                       # (peer, device index list, count)
         for p in range(comm.size):
-            if p != comm.rank and wants[p] and comm.rank in wants[p]:
+            if (p != comm.rank or comm.force) and wants[p] and comm.rank in wants[p]:
                 idx = np.ascontiguousarray(wants[p][comm.rank])
                 dbuf = comm.buffer(idx.nbytes)
                 dbuf.copy_(comm.torch.from_numpy(idx.view(np.uint8)))

@@ -11,7 +11,157 @@ Chebyshev residual polynomial), as the solver requires of a preconditioner
 runs using it are reported separately from the reference's.
 """
 
+import ctypes
+
 import numpy as np
+
+from ... import _lib
+
+
+class TriangularChain:
+    """X = T_k^-1 ... T_1^-1 B on the device for sparse triangular factors given as SciPy matrices
+    (level-scheduled solves on the whole n x m block: rlh_sptrsv_create / rlh_sptrsv_solve_chain).
+
+    factors: list of (matrix, lower, unit_diag); a unit-diagonal factor must not store its diagonal.
+    perm_in / perm_out: optional row permutations (row r of the internal block is row perm_in[r] of
+    B, and is written to row perm_out[r] of X)."""
+
+    def __init__(self, factors, dtype, perm_in=None, perm_out=None):
+        import scipy.sparse as scs
+        L = _lib.lib()
+        self._dtype = np.dtype(dtype).type
+        self._code = _lib.dtype_code(self._dtype)
+        self._ops = []
+        self._n = None
+        self.levels, self.nnz = [], []
+        for mat, lower, unit in factors:
+            a = scs.csr_matrix(mat, dtype=self._dtype)
+            a.sort_indices()
+            n = a.shape[0]
+            if self._n not in (None, n) or a.shape[0] != a.shape[1]:
+                raise ValueError('the triangular factors must be square and of one size')
+            self._n = n
+            indptr = np.ascontiguousarray(a.indptr, dtype=np.int64)
+            indices = np.ascontiguousarray(a.indices, dtype=np.int32)
+            values = np.ascontiguousarray(a.data)
+            h = ctypes.c_void_p()
+            _lib.check(L.rlh_sptrsv_create(ctypes.byref(h), self._code, n, _lib.host_ptr(indptr), _lib.host_ptr(indices),
+                                           _lib.host_ptr(values), 1 if lower else 0, 1 if unit else 0))
+            self._ops.append(h)
+            nnz, lev, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(L.rlh_sptrsv_info(h, ctypes.byref(nnz), ctypes.byref(lev), ctypes.byref(nb)))
+            self.levels.append(int(lev.value))
+            self.nnz.append(int(nnz.value))
+        self._arr = (ctypes.c_void_p * len(self._ops))(*[h.value for h in self._ops])
+        self._perms = []
+        for perm in (perm_in, perm_out):
+            if perm is None:
+                self._perms.append(None)
+                continue
+            from .memory import DeviceBuffer
+            host = np.ascontiguousarray(perm, dtype=np.int64)
+            buf = DeviceBuffer(host.nbytes, zero=False)
+            _lib.check(L.rlh_h2d(buf.ptr, _lib.host_ptr(host), host.nbytes))
+            self._perms.append(buf)
+
+    def __del__(self):
+        ops, self._ops = getattr(self, '_ops', []), []
+        for h in ops:
+            try:
+                _lib.library().rlh_sptrsv_destroy(h)
+            except Exception:
+                pass
+
+    def size(self):
+        return self._n
+
+    def algorithmic_bytes(self, m):
+        """Entries of the factors (value + 4-byte column index) + one read of B and one write of X."""
+        es = np.dtype(self._dtype).itemsize
+        return sum(self.nnz) * (es + 4) + 2 * self._n * m * es
+
+    def solve(self, b, x):
+        """x = chain^-1 b for Vectors windows of equal size (b may be x)."""
+        m = b.nvec()
+        if m != x.nvec():
+            raise ValueError('Numbers of input and output vectors differ')
+        if b.data_type() != self._dtype or x.data_type() != self._dtype:
+            raise ValueError('Factors and vectors data types differ')
+        n = getattr(b, 'local_dimension', b.dimension)()
+        if n != self._n:
+            raise ValueError('Factors and vectors dimensions incompatible')
+        pin, pout = self._perms
+        _lib.check(_lib.lib().rlh_sptrsv_solve_chain(
+            len(self._ops), self._arr, pin.ptr if pin else None, pout.ptr if pout else None, m,
+            b.data_ptr(), b.ld(), x.data_ptr(), x.ld()))
+
+    apply = solve
+
+
+def ilut(matrix, tol=1e-6, maxfil=None):
+    """Dual-threshold incomplete LU of a SciPy sparse matrix (rlh_ilut_factor: the host
+    factorisation behind IncompleteLU; counterpart of mkl dcsrilut, mkl_wrap.py:305-331).
+    Returns (L strictly lower with unit diagonal implied, U upper) as CSR in double / complex double."""
+    import scipy.sparse as scs
+    a = scs.csr_matrix(matrix)
+    a.sort_indices()
+    n = a.shape[0]
+    cplx = np.iscomplexobj(a.data)
+    dt = np.complex128 if cplx else np.float64
+    if maxfil is None:
+        maxfil = min(n - 1, a.nnz // max(n, 1))
+    indptr = np.ascontiguousarray(a.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(a.indices, dtype=np.int32)
+    values = np.ascontiguousarray(a.data, dtype=dt)
+    L = _lib.library()                         # host-only entry points: no device needed
+    f = ctypes.c_void_p()
+    _lib.check(L.rlh_ilut_factor(ctypes.byref(f), _lib.DTYPE_CODE[dt], n, _lib.host_ptr(indptr), _lib.host_ptr(indices),
+                                 _lib.host_ptr(values), float(tol), int(maxfil)))
+    try:
+        nl, nu = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L.rlh_factors_nnz(f, ctypes.byref(nl), ctypes.byref(nu)))
+        out = []
+        for which, nnz in ((0, nl.value), (1, nu.value)):
+            ip = np.zeros(n + 1, dtype=np.int64)
+            ix = np.zeros(max(nnz, 1), dtype=np.int32)
+            va = np.zeros(max(nnz, 1), dtype=dt)
+            _lib.check(L.rlh_factors_get(f, which, _lib.host_ptr(ip), _lib.host_ptr(ix), _lib.host_ptr(va)))
+            m = scs.csr_matrix((va[:nnz], ix[:nnz], ip), shape=(n, n))
+            m.sort_indices()
+            out.append(m)
+    finally:
+        L.rlh_factors_destroy(f)
+    return out[0], out[1]
+
+
+class IncompleteLU:
+    """Incomplete LU preconditioner applied on the device (same surface as the reference's
+    IncompleteLU, raleigh/algebra/sparse_mkl.py:122-140: construct from the matrix, `factorize(tol,
+    max_fill)`, `apply(x, y)`).  The reference factorises with mkl dcsrilut and applies two
+    mkl_dcsrtrsv per vector on the host; here the same dual-threshold ILUT runs once on the host
+    (rlh_ilut_factor) and the two triangular solves run on the whole block in HBM."""
+
+    def __init__(self, matrix):
+        import scipy.sparse as scs
+        self._a = scs.csr_matrix(matrix)
+        self._a.sort_indices()
+        self._chain = None
+
+    def factorize(self, tol=1e-6, max_fill=1):
+        n = self._a.shape[0]
+        maxfil = min(n - 1, (self._a.nnz // n) * max_fill)       # mkl_wrap.py:306
+        lo, up = ilut(self._a, tol, maxfil)
+        self._chain = TriangularChain([(lo, True, True), (up, False, False)], self._a.dtype)
+        self.fill = (lo.nnz + up.nnz) / float(self._a.nnz)
+        self.levels = tuple(self._chain.levels)
+
+    def chain(self):
+        return self._chain
+
+    def apply(self, x, y):
+        if self._chain is None:
+            self.factorize()
+        self._chain.solve(x, y)
 
 
 def gershgorin_upper_bound(matrix):

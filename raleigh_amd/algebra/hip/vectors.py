@@ -326,6 +326,10 @@ class Vectors:
             q2.shape[0], other._ptr(), other._ld, _lib.host_ptr(q2), ma + mb, 1,
             ma, out_a._ptr(), out_a._ld, mb, out_b._ptr(), out_b._ld))
 
+    def reduction_batch(self):
+        """A ReductionBatch for blocks of this type and dimension."""
+        return ReductionBatch(self)
+
     def lincomb(self, a, x, b, y):
         """self[i] = a[i] * x[i] + b[i] * y[i] (a, b scalars or per-vector arrays); self may be x or y.
         One pass instead of copy + add (solver.py:942-952)."""
@@ -438,6 +442,90 @@ class Vectors:
             dst.copy(self)
         # X = W S Vr^H = W S v^T  =>  v = conj(Vr); the reference returns conj(v) = Vr
         return S.astype(real_dt), Vrh.conj().T.astype(self._dtype)
+
+
+class ReductionBatch:
+    """Several Gram / dots reductions evaluated with ONE host synchronisation (and, row-sharded,
+    one all-reduce): the kernels write their results side by side into a device buffer that is
+    fetched once by run().  The reference issues every `dot` / `dots` as its own blocking call
+    (raleigh/core/solver.py:854-861, 1321-1339, 1376-1381, 1444-1447 are back-to-back pairs on
+    shared operands): SURVEY 8(f).3 "fused Gram pairs".
+
+    gram(rights, lefts) requests [lefts...]^H [rights...] (the blocks of each list side by side:
+    one pass, every block read once), i.e. the stacked `r.dot(l)` for r in rights, l in lefts;
+    dots(a, b) requests a.dots(b).  run() returns the results in request order."""
+
+    def __init__(self, proto):
+        self._proto = proto
+        self._reqs = []
+
+    def gram(self, rights, lefts):
+        rights = [rights] if isinstance(rights, Vectors) else list(rights)
+        lefts = [lefts] if isinstance(lefts, Vectors) else list(lefts)
+        if not 1 <= len(rights) <= 4 or not 1 <= len(lefts) <= 4:
+            raise ValueError('1 to 4 blocks per side')
+        self._reqs.append(('gram', rights, lefts))
+        return len(self._reqs) - 1
+
+    def dots(self, a, b):
+        self._reqs.append(('dots', a, b))
+        return len(self._reqs) - 1
+
+    def _buffer(self, nbytes):
+        """Device buffer the results are written to (a communication buffer for row shards)."""
+        lib = _lib.library()                   # (the buffer lives and dies with the library object)
+        buf = getattr(lib, '_rlh_reduction_scratch', None)
+        if buf is None or buf.nbytes < nbytes:
+            buf = DeviceBuffer(max(nbytes, 1 << 16), zero=False)
+            lib._rlh_reduction_scratch = buf
+        return buf.ptr
+
+    def _collect(self, ptr, count):
+        """The `count` result elements at `ptr` as a host array: one synchronisation."""
+        p = self._proto
+        out = np.empty((count,), dtype=p.data_type())
+        _lib.check(_lib.lib().rlh_fetch(_lib.host_ptr(out), ptr, out.nbytes))
+        return out
+
+    def run(self):
+        import ctypes
+        p = self._proto
+        L = _lib.lib()
+        es, code = p._es, p._code
+        n = p._vdim
+        shapes, count = [], 0
+        for kind, a, b in self._reqs:
+            if kind == 'gram':
+                shp = (sum(v.nvec() for v in b), sum(v.nvec() for v in a))
+            else:
+                shp = (a.nvec(),)
+            shapes.append((count, shp))
+            count += int(np.prod(shp))
+        if count == 0:
+            return [np.zeros(shp, dtype=p.data_type()) for _, shp in shapes]
+        base = self._buffer(count * es)
+        for (kind, a, b), (off, shp) in zip(self._reqs, shapes):
+            if int(np.prod(shp)) == 0:
+                continue
+            dst = base + off * es
+            if kind == 'dots':
+                _lib.check(L.rlh_dots(code, n, a.nvec(), a._ptr(), a._ld, b._ptr(), b._ld, dst, None))
+            elif len(a) == 1 and len(b) == 1:
+                _lib.check(L.rlh_gram(code, n, a[0].nvec(), a[0]._ptr(), a[0]._ld, b[0].nvec(), b[0]._ptr(), b[0]._ld,
+                                      dst, None))
+            else:
+                def pack(vs):
+                    vs = [v for v in vs if v.nvec() > 0]
+                    ptrs = (ctypes.c_void_p * len(vs))(*[v._ptr() for v in vs])
+                    lds = np.array([v._ld for v in vs], dtype=np.int64)
+                    ms = np.array([v.nvec() for v in vs], dtype=np.int64)
+                    return len(vs), ptrs, lds, ms
+                nx, xp, xl, xm = pack(a)
+                ny, yp, yl, ym = pack(b)
+                _lib.check(L.rlh_gram_multi(code, n, nx, xp, _lib.host_ptr(xl), _lib.host_ptr(xm), ny, yp,
+                                            _lib.host_ptr(yl), _lib.host_ptr(ym), dst, None))
+        flat = self._collect(base, count)
+        return [flat[off:off + int(np.prod(shp))].reshape(shp).copy() for off, shp in shapes]
 
 
 def _is_matrix(arg):

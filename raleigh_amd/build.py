@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'librlhip.so')
 SOURCES = ['context', 'gram', 'update', 'spmm', 'spmm_wide_build', 'spmm_wide_s', 'spmm_wide_d', 'spmm_wide_c',
-           'spmm_wide_z', 'dense']
+           'spmm_wide_z', 'sptrsv', 'dense']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
 

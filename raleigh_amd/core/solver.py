@@ -352,6 +352,10 @@ class Solver:
         opA, opB, opP = problem.A(), problem.B(), self.__P
         # one-pass forms of multiply+add / copy+add when the Vectors type offers them
         fused = hasattr(vector, 'combine') and hasattr(vector, 'lincomb')
+        # several Gram / dots reductions with ONE host synchronisation (and one all-reduce when the
+        # rows are sharded): the reference issues them as back-to-back blocking calls on shared
+        # operands (solver.py:854-861, 1321-1339, 1376-1381, 1444-1447)
+        batched = fused and hasattr(vector, 'reduction_batch') and not pro
 
         # ---- work blocks: the active vectors always occupy the first nx slots
         X = vector.new_vectors(m)
@@ -466,8 +470,22 @@ class Solver:
                 print('------------- iteration %d' % self.iteration)
 
             select_all(nx, X, AX, BX)
-            XAX = AX.dot(BX) if pro else AX.dot(X)
-            XBX = BX.dot(X)
+            speculative = None
+            if batched and Xc.nvec() == 0:
+                # One round trip for the Ritz-pair check AND the residual norms: the residuals are
+                # formed with the Ritz values of the last Rayleigh-Ritz step (which the recomputed
+                # Rayleigh quotients reproduce to rounding unless orthogonality was lost -- then the
+                # restart below recomputes everything) while the Gram pair is in flight.
+                W.select(nx)
+                W.lincomb(1.0, AX, -np.asarray(lmdx[:nx]), BX if gen else X)
+                rb = X.reduction_batch()
+                rb.gram([X], [AX, BX] if not std else [AX, X])
+                rb.dots(W, W)
+                G2, speculative = rb.run()
+                XAX, XBX = G2[:nx], G2[nx:]
+            else:
+                XAX = AX.dot(BX) if pro else AX.dot(X)
+                XBX = BX.dot(X)
             new_lmd = np.real(XAX.diagonal() / XBX.diagonal())
 
             # ---- sanity of the Ritz pairs; restart through an SVD-orthonormalisation if lost
@@ -479,6 +497,7 @@ class Solver:
                     print('Ritz vectors non-orthonormality: %.1e' % rv_no)
                     print('restarting...')
                 rec, nz = 0, 0
+                speculative = None
                 X.svd()
                 if not std:
                     opB.apply(X, BX)
@@ -509,19 +528,25 @@ class Solver:
             # ---- residuals W = A X - (B) X lmd, orthogonalised against the locked vectors
             W.select(nx)
             Y.select(nx)
-            if fused:           # one pass: W = AX - (B)X diag(lmd)
-                W.lincomb(1.0, AX, -lmd[:nx], BX if gen else X)
+            if speculative is not None and np.all(np.abs(new_lmd - lmdx[:nx]) <= np.maximum(
+                    1e-3 * np.sqrt(np.abs(speculative)), 1e-14 * np.amax(np.abs(lmdx[:nx])))):
+                # W and its norms are already there: the Ritz values it was formed with differ from the
+                # recomputed ones by less than 0.1 % of the residual norms
+                s = speculative
             else:
-                AX.copy(W)
-                W.add(BX if gen else X, -lmd[:nx])
-            if Xc.nvec() > 0:
-                project_out_locked(W, BXc if pro else Xc, BXc if gen else Xc)
-            if pro:
-                W.copy(Y)
-                opB.apply(Y, W)
-                s = W.dots(Y)
-            else:
-                s = W.dots(W)
+                if fused:           # one pass: W = AX - (B)X diag(lmd)
+                    W.lincomb(1.0, AX, -lmd[:nx], BX if gen else X)
+                else:
+                    AX.copy(W)
+                    W.add(BX if gen else X, -lmd[:nx])
+                if Xc.nvec() > 0:
+                    project_out_locked(W, BXc if pro else Xc, BXc if gen else Xc)
+                if pro:
+                    W.copy(Y)
+                    opB.apply(Y, W)
+                    s = W.dots(Y)
+                else:
+                    s = W.dots(W)
             res[:nx] = np.sqrt(np.abs(s))
 
             self._kinematic_estimates(hist, rec, nx)
@@ -668,12 +693,21 @@ class Solver:
 
             if nz > 0:          # conjugate Y against the previous search directions Z
                 select_all(nz, Z, AZ, BZ)
-                ZAY = W.dot(AZ) if pro else Y.dot(AZ)
-                ZBY = Y.dot(BZ)
+                if batched:     # ZAY, ZBY and the two sets of norms: one round trip
+                    rb = Y.reduction_batch()
+                    rb.gram([Y], [AZ, BZ])
+                    rb.dots(Y, Y)
+                    rb.dots(Z, Z)
+                    G2, dy, dz = rb.run()
+                    ZAY, ZBY = G2[:nz], G2[nz:]
+                    sy, sz = np.sqrt(np.abs(dy)), np.sqrt(np.abs(dz))
+                else:
+                    ZAY = W.dot(AZ) if pro else Y.dot(AZ)
+                    ZBY = Y.dot(BZ)
+                    sy = np.sqrt(np.abs(Y.dots(Y)))
+                    sz = np.sqrt(np.abs(Z.dots(Z)))
                 Num = ZAY - ZBY * lmd_y[None, :]
                 Den = np.asarray(lmdz)[:, None] - lmd_y[None, :]
-                sy = np.sqrt(np.abs(Y.dots(Y)))
-                sz = np.sqrt(np.abs(Z.dots(Z)))
                 with np.errstate(divide='ignore', invalid='ignore'):
                     Beta = np.where(np.abs(Num) >= 100 * (sy[None, :] / sz[:, None]) * np.abs(Den), 0.0, Num / Den)
                 Beta = np.nan_to_num(Beta).astype(dt)
@@ -698,21 +732,38 @@ class Solver:
                     BY.add(BXc, -1.0, Q)
 
             # ---- B-Gram matrix of (X, Y), Y normalised
-            if std:
-                Y.scale(np.sqrt(np.abs(Y.dots(Y))))
+            if batched and std:
+                # [X | Y]^H Y in one pass and one round trip; the normalisation of Y is applied to the
+                # small matrices on the host and to the block on the device
+                rb = Y.reduction_batch()
+                rb.gram([Y], [X, Y] if nx_act > 0 else [Y])
+                G2 = rb.run()[0]
+                YBY = G2[nx_act:]
+                sn = np.sqrt(np.abs(np.real(YBY.diagonal())))
+                Y.scale(sn)
+                sn = np.where(sn == 0, 1.0, sn)
+                YBY = YBY / sn[:, None] / sn[None, :]
+                if nx_act > 0:
+                    XBY = G2[:nx_act] / sn[None, :]
+                    GB = np.block([[XBX, XBY], [XBY.conj().T, YBY]])
+                else:
+                    GB = YBY
             else:
-                BY.select(ny)
-                if not pro:
-                    opB.apply(Y, BY)
-                s = np.sqrt(np.abs(BY.dots(Y)))
-                Y.scale(s)
-                BY.scale(s)
-            YBY = BY.dot(Y)
-            if nx_act > 0:
-                XBY = BY.dot(X)
-                GB = np.block([[XBX, XBY], [XBY.conj().T, YBY]])
-            else:
-                GB = YBY
+                if std:
+                    Y.scale(np.sqrt(np.abs(Y.dots(Y))))
+                else:
+                    BY.select(ny)
+                    if not pro:
+                        opB.apply(Y, BY)
+                    s = np.sqrt(np.abs(BY.dots(Y)))
+                    Y.scale(s)
+                    BY.scale(s)
+                YBY = BY.dot(Y)
+                if nx_act > 0:
+                    XBY = BY.dot(X)
+                    GB = np.block([[XBX, XBY], [XBY.conj().T, YBY]])
+                else:
+                    GB = YBY
 
             U, ind, dropped = _pivoted_cholesky(GB, nx_act, 1e-3 if single else 1e-8)
             if dropped > 0 and verb > 0:
@@ -751,8 +802,14 @@ class Solver:
                 XAY = AY.dot(BX) if nx_act > 0 else None
             else:
                 opA.apply(Y, AY)
-                YAY = AY.dot(Y)
-                XAY = AY.dot(X) if nx_act > 0 else None
+                if batched and nx_act > 0:      # [X | Y]^H AY: one pass, one round trip
+                    rb = AY.reduction_batch()
+                    rb.gram([AY], [X, Y])
+                    G2 = rb.run()[0]
+                    XAY, YAY = G2[:nx_act], G2[nx_act:]
+                else:
+                    YAY = AY.dot(Y)
+                    XAY = AY.dot(X) if nx_act > 0 else None
             YAY = YAY[np.ix_(perm, perm)]                     # to the pivoted order of U
             if nx_act > 0:
                 XAY = XAY[:, perm]

@@ -39,6 +39,11 @@ template <> struct Mfma16<float> {
   static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
 };
 
+// A window made of several blocks side by side (rlh_gram_multi: [AX | X]^H X in one pass):
+// segment k covers the columns [c0, next c0) of the concatenated window.
+struct GramSeg { const void *p; int64_t ld; int c0; };
+constexpr int kGramSegs = 4;
+
 struct GramArgs {
   const void *X, *Y;
   int64_t ldx, ldy;   // in elements of T
@@ -48,6 +53,8 @@ struct GramArgs {
   int npj;            // number of X panels
   int64_t nchunks;
   void *partials;     // [npanels][gridDim.x][VY][VX] reals
+  int nxs, nys;       // segments of the X / Y window (MULTI kernels only)
+  GramSeg xs[kGramSegs], ys[kGramSegs];
 };
 
 // (three resident workgroups per CU measured faster in sustained back-to-back use than the four that
@@ -60,7 +67,8 @@ struct GramArgs {
 //         at compile time, so the loads of a chunk are straight-line code and the loop keeps TWO
 //         chunks in flight in two register sets (the compiler emits counted vmcnt waits only for
 //         straight-line load groups: with a predicate per load it waits for vmcnt(0)).
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE>
+// MULTI: the windows are concatenations of up to kGramSegs blocks (general loop, MODE 0, only).
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false>
 __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) void gram_kernel(GramArgs a) {
   using T = typename DType<DT>::T;
   using R = typename DType<DT>::R;
@@ -107,12 +115,37 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
   const int tcol = tid / UPC, tk = tid % UPC;
   const int uy = same_panel ? 0 : UYQ;           // wave-uniform
 
+  // (MULTI: the row-independent part of every piece address -- segment, column -- is fixed per
+  // thread and found once, in front of the chunk loop)
+  const R *pbase[MULTI ? UPT : 1];
+  if constexpr (MULTI) {
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const bool isY = q < uy;
+      int gcol = (isY ? cy0 + q * CPQ : cx0 + (q - uy) * CPQ) + tcol;
+      const int mcols = isY ? a.my : a.mx;
+      gcol = gcol < mcols ? gcol : mcols - 1;
+      const GramSeg *segs = isY ? a.ys : a.xs;
+      const int ns = isY ? a.nys : a.nxs;
+      const void *p = segs[0].p;
+      int64_t ld = segs[0].ld;
+      int c0 = 0;
+#pragma unroll
+      for (int k = 1; k < kGramSegs; ++k)
+        if (k < ns && gcol >= segs[k].c0) { p = segs[k].p; ld = segs[k].ld; c0 = segs[k].c0; }
+      pbase[q] = reinterpret_cast<const R *>(p) + (int64_t)(gcol - c0) * ld * NC + tk * RPU;
+    }
+  }
   auto piece_ptr = [&](int q, int64_t row0) -> const R * {
-    const bool isY = q < uy;
-    int gcol = (isY ? cy0 + q * CPQ : cx0 + (q - uy) * CPQ) + tcol;
-    const int mcols = isY ? a.my : a.mx;
-    gcol = gcol < mcols ? gcol : mcols - 1;
-    return (isY ? Yr : Xr) + ((int64_t)gcol * (isY ? a.ldy : a.ldx) + row0) * NC + tk * RPU;
+    if constexpr (MULTI) {
+      return pbase[q] + row0 * NC;
+    } else {
+      const bool isY = q < uy;
+      int gcol = (isY ? cy0 + q * CPQ : cx0 + (q - uy) * CPQ) + tcol;
+      const int mcols = isY ? a.my : a.mx;
+      gcol = gcol < mcols ? gcol : mcols - 1;
+      return (isY ? Yr : Xr) + ((int64_t)gcol * (isY ? a.ldy : a.ldx) + row0) * NC + tk * RPU;
+    }
   };
 
   auto load_chunk = [&](int64_t chunk) {
@@ -348,12 +381,12 @@ __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int 
 }
 
 // Resident workgroups per CU for one instantiation (registers + LDS), asked once.
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false>
 static int gram_blocks_per_cu() {
   static int cached = 0;
   if (cached == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE>, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI>, 256, 0) != hipSuccess ||
         nb < 1)
       nb = 1;
     cached = nb > 8 ? 8 : nb;
@@ -369,7 +402,7 @@ static inline int pick_tiles(int v) {   // 16x16 tiles per panel side: 1, 2 or 4
   return 4;
 }
 
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false>
 static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, void *d_out) {
   using R = typename DType<DT>::R;
   Context &c = ctx();
@@ -377,14 +410,14 @@ static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, vo
   const int npanels = npi * npj;
   // the grid is sized to what is resident at once: every workgroup strides over the row
   // chunks, so a second, partially filled round of workgroups would only add a tail
-  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE>() / npanels;
+  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE, MULTI>() / npanels;
   if (nbx < 1) nbx = 1;
   if (nbx > a.nchunks) nbx = a.nchunks;
   const size_t part_bytes = sizeof(R) * VY * VX;
   while (nbx > 1 && (size_t)nbx * npanels * part_bytes > kWorkspaceBytes) nbx /= 2;
   RLH_REQUIRE((size_t)nbx * npanels * part_bytes <= kWorkspaceBytes,
               "rlh_gram: %lld x %lld result exceeds the reduction workspace", (long long)my, (long long)mx);
-  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE>), dim3((unsigned)nbx, (unsigned)npanels), dim3(256), 0,
+  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI>), dim3((unsigned)nbx, (unsigned)npanels), dim3(256), 0,
                      c.stream, a);
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
@@ -443,6 +476,50 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   RLH_GRAM_CASE(4, 1) RLH_GRAM_CASE(4, 2) RLH_GRAM_CASE(4, 4)
 #undef RLH_GRAM_CASE
   set_error("rlh_gram: no kernel for panel %d x %d", PI, PJ);
+  return 1;
+}
+
+// Gram of two concatenated windows: G = [Y_0 | Y_1 | ...]^H [X_0 | X_1 | ...] in one pass (every block
+// is read once: [AX | X]^H X costs three block reads where two separate Grams cost four).
+template <int DT>
+static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_t *ldx, const int64_t *mx, int ny,
+                           const void *const *Y, const int64_t *ldy, const int64_t *my, void *d_out) {
+  using R = typename DType<DT>::R;
+  constexpr int NC = DType<DT>::cplx ? 2 : 1;
+  Context &c = ctx();
+  GramArgs a;
+  const int64_t es = dtype_size(DT);
+  bool aligned = true;
+  int64_t mxt = 0, myt = 0;
+  for (int k = 0; k < nx; ++k) {
+    a.xs[k] = GramSeg{X[k], ldx[k], (int)mxt};
+    mxt += mx[k];
+    aligned = aligned && aligned16(X[k], ldx[k], es);
+  }
+  for (int k = 0; k < ny; ++k) {
+    a.ys[k] = GramSeg{Y[k], ldy[k], (int)myt};
+    myt += my[k];
+    aligned = aligned && aligned16(Y[k], ldy[k], es);
+  }
+  for (int k = nx; k < kGramSegs; ++k) a.xs[k] = GramSeg{nullptr, 0, 1 << 30};
+  for (int k = ny; k < kGramSegs; ++k) a.ys[k] = GramSeg{nullptr, 0, 1 << 30};
+  a.nxs = nx; a.nys = ny;
+  const int vx = (int)mxt * NC, vy = (int)myt * NC;
+  const int PI = pick_tiles(vy), PJ = pick_tiles(vx);
+  const int npi = (vy + PI * 16 - 1) / (PI * 16), npj = (vx + PJ * 16 - 1) / (PJ * 16);
+  a.X = X[0]; a.Y = Y[0]; a.ldx = ldx[0]; a.ldy = ldy[0]; a.n = n; a.mx = (int)mxt; a.my = (int)myt;
+  a.same = 0; a.npj = npj; a.partials = c.work;
+  const int ROWS = 512 / (int)sizeof(R);
+  a.nchunks = (n + ROWS - 1) / ROWS;
+#define RLH_GRAM_MCASE(pi, pj)                                                                        \
+  if (PI == pi && PJ == pj)                                                                           \
+    return aligned ? gram_launch<DT, pi, pj, true, 0, true>(a, npi, npj, myt, mxt, d_out)             \
+                   : gram_launch<DT, pi, pj, false, 0, true>(a, npi, npj, myt, mxt, d_out);
+  RLH_GRAM_MCASE(1, 1) RLH_GRAM_MCASE(1, 2) RLH_GRAM_MCASE(1, 4)
+  RLH_GRAM_MCASE(2, 1) RLH_GRAM_MCASE(2, 2) RLH_GRAM_MCASE(2, 4)
+  RLH_GRAM_MCASE(4, 1) RLH_GRAM_MCASE(4, 2) RLH_GRAM_MCASE(4, 4)
+#undef RLH_GRAM_MCASE
+  set_error("rlh_gram_multi: no kernel for panel %d x %d", PI, PJ);
   return 1;
 }
 
@@ -664,6 +741,39 @@ int rlh_gram(int dtype, int64_t n, int64_t mx, const void *X, int64_t ldx, int64
     RLH_HIP(hipMemsetAsync(d_out, 0, bytes, ctx().stream));
   } else {
     RLH_DISPATCH(dtype, gram_impl, n, mx, X, ldx, my, Y, ldy, d_out)
+  }
+  if (rc) return rc;
+  if (h_out) return fetch_result(h_out, d_out, bytes);
+  return 0;
+}
+
+int rlh_gram_multi(int dtype, int64_t n, int nx, const void *const *X, const int64_t *ldx, const int64_t *mx, int ny,
+                   const void *const *Y, const int64_t *ldy, const int64_t *my, void *d_out, void *h_out) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_gram_multi: unknown dtype %d", dtype);
+  RLH_REQUIRE(nx >= 1 && nx <= kGramSegs && ny >= 1 && ny <= kGramSegs, "rlh_gram_multi: 1 to %d blocks per window", kGramSegs);
+  RLH_REQUIRE(n >= 0 && X && ldx && mx && Y && ldy && my, "rlh_gram_multi: bad arguments");
+  int64_t mxt = 0, myt = 0;
+  for (int k = 0; k < nx; ++k) {
+    RLH_REQUIRE(mx[k] >= 1 && X[k] && ldx[k] >= n, "rlh_gram_multi: bad block %d of the right window", k);
+    mxt += mx[k];
+  }
+  for (int k = 0; k < ny; ++k) {
+    RLH_REQUIRE(my[k] >= 1 && Y[k] && ldy[k] >= n, "rlh_gram_multi: bad block %d of the left window", k);
+    myt += my[k];
+  }
+  RLH_REQUIRE(mxt <= 32768 && myt <= 32768, "rlh_gram_multi: more than 32768 vectors in a window");
+  RLH_REQUIRE(d_out || h_out, "rlh_gram_multi: no output buffer");
+  const size_t bytes = (size_t)(mxt * myt * dtype_size(dtype));
+  if (!d_out) {
+    if (int rc = ensure_result(bytes)) return rc;
+    d_out = ctx().result_hd;
+  }
+  int rc = 0;
+  if (n == 0) {
+    RLH_HIP(hipMemsetAsync(d_out, 0, bytes, ctx().stream));
+  } else {
+    RLH_DISPATCH(dtype, gram_multi_impl, n, nx, X, ldx, mx, ny, Y, ldy, my, d_out)
   }
   if (rc) return rc;
   if (h_out) return fetch_result(h_out, d_out, bytes);

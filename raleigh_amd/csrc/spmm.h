@@ -23,7 +23,7 @@ struct WideMeta {
   int64_t eoff;            // first entry chunk of the block (a chunk = 8 entry slots of each of the 256 rows)
   int32_t goff;            // first staging group of the block in `gsrc`
   int16_t nchunks;         // entry chunks per row
-  int16_t ng;              // staging groups (64 columns each) per vector
+  int16_t ng;              // staging groups (kWideGroup columns each) per vector
 };
 
 struct WideSched {         // launch order built for one (resident workgroups, part, n_own) combination
@@ -120,6 +120,7 @@ __device__ __forceinline__ c64 sub_of(c64 a, c64 b) { return c64{a.re - b.re, a.
 template <typename T, int EPL> struct VecU { T e[EPL]; };
 template <typename T, int EPL> struct alignas(16) VecA { T e[EPL]; };
 typedef unsigned rlh_u32x4e __attribute__((ext_vector_type(4)));
+typedef unsigned rlh_u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte piece at 4-byte alignment
 
 // ---- host side: column windows of a block of rows
 struct Win { int32_t start, len, off; };        // off: position of the window in the staged image
@@ -127,18 +128,18 @@ struct Win { int32_t start, len, off; };        // off: position of the window i
 // The columns referenced by rows [r0, r1) merged into windows: holes of at most `gap` columns are
 // bridged, a window starts on a multiple of 8 columns (16-byte staging loads: a piece is 2 to 8
 // elements and must not lie across the own / halo boundary of a row shard) and is padded to whole
-// 64-column staging groups that stay inside the column range where the matrix is wide enough (a
+// staging groups of `gs` columns that stay inside the column range where the matrix is wide enough (a
 // window at the far end is moved left instead of being padded past the last column).  Returns the
-// number of staged columns (a multiple of `round_groups` * 64); `ws` is left with at least one window.
+// number of staged columns (a multiple of `round_groups` * gs); `ws` is left with at least one window.
 static inline int32_t find_windows(const int64_t *indptr, const int32_t *indices, int64_t r0, int64_t r1, int64_t nc,
-                                   int gap, int round_groups, std::vector<Win> &ws) {
+                                   int gap, int gs, int round_groups, std::vector<Win> &ws) {
   std::vector<int32_t> cols(indices + indptr[r0], indices + indptr[r1]);
   std::sort(cols.begin(), cols.end());
   cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
   ws.clear();
   auto place = [&](int64_t first, int64_t last, int64_t &start, int64_t &padded) {
     start = first & ~(int64_t)7;
-    padded = (last - start + 1 + 63) / 64 * 64;
+    padded = (last - start + gs) / gs * gs;
     if (start + padded > nc && nc >= padded) start = nc - padded;
   };
   for (size_t i = 0; i < cols.size();) {
@@ -158,14 +159,14 @@ static inline int32_t find_windows(const int64_t *indptr, const int32_t *indices
   int32_t off = 0;
   for (Win &w : ws) {
     w.off = off;
-    off += (w.len + 63) / 64 * 64;
+    off += (w.len + gs - 1) / gs * gs;
     if (off > (1 << 24)) break;
   }
   if (ws.empty()) {                            // a block of empty rows still stages one group
     ws.push_back(Win{0, 1, 0});
-    off = 64;
+    off = gs;
   }
-  const int32_t unit = 64 * round_groups;
+  const int32_t unit = gs * round_groups;
   return (off + unit - 1) / unit * unit;
 }
 
@@ -180,10 +181,10 @@ static inline int32_t staged_position(const std::vector<Win> &ws, int32_t c) {
 }
 
 // first column of every staging group of a block (surplus groups repeat the last)
-static inline void fill_group_sources(const std::vector<Win> &ws, int32_t ngroups, int32_t *gsrc) {
+static inline void fill_group_sources(const std::vector<Win> &ws, int32_t ngroups, int gs, int32_t *gsrc) {
   int32_t filled = 0, last = 0;
   for (const Win &w : ws)
-    for (int32_t g = 0; g < (w.len + 63) / 64; ++g, ++filled) gsrc[w.off / 64 + g] = last = w.start + 64 * g;
+    for (int32_t g = 0; g < (w.len + gs - 1) / gs; ++g, ++filled) gsrc[w.off / gs + g] = last = w.start + gs * g;
   for (; filled < ngroups; ++filled) gsrc[filled] = last;
 }
 
@@ -297,7 +298,10 @@ static inline void well_schedule(const std::vector<std::vector<Win>> &wins, int6
 // ---- the interleaved layout (spmm_wide_build.hip, spmm_wide_{s,d,c,z}.hip)
 constexpr int kWideRows = 256;                 // rows per block = threads per workgroup
 constexpr int kWideLdsBytes = 160 * 1024;      // LDS of a CU
-constexpr int kWideHeader = 512;               // the block's staging-group columns, in front of the image
+constexpr int kWideGroup = 16;                 // columns per staging group (windows are padded to whole groups)
+constexpr int kWideGroupShift = 4;
+constexpr int kWideHeader = 1024;              // a block's staging-group columns (<= 256); two of them in front of the image
+constexpr int kWidePadChunks = 4;              // entry chunks allocated past the last block (the prefetch runs ahead)
 int wide_stride(int nv, int es);
 int wide_min_nv(int dtype);
 int wide_sched(rlh_csr *h, int slots, int part, int64_t n_own, const int32_t **sched, int64_t *len, int *grid);

@@ -202,7 +202,8 @@ __host__ __device__ inline int64_t well_val_index(int64_t eoff, int t, int l) {
 __host__ __device__ inline int64_t well_idx_index(int64_t eoff, int t, int l) {
   return (eoff + (t / 8) * 8) * 1024 + (int64_t)l * 8 + (t % 8);
 }
-// the row's WMAX values and positions (positions beyond `width` and their values come back as 0)
+// the row's WMAX values and positions (the host pads every row to WMAX slots: value 0 at the position of
+// the row's own first entry, so a padding slot never touches a column the row does not reference)
 template <typename T, int WMAX>
 __device__ __forceinline__ void well_load_entries(const T *__restrict__ vals, const uint16_t *__restrict__ idx,
                                                   int64_t eoff, int tid, int width, T (&v)[WMAX], unsigned (&pos)[WMAX]) {
@@ -213,14 +214,14 @@ __device__ __forceinline__ void well_load_entries(const T *__restrict__ vals, co
     union { rlh_u32x4e u; T t[VPG]; } piece;
     piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(vals + well_val_index<T>(eoff, g * VPG, tid)));
 #pragma unroll
-    for (int k = 0; k < VPG; ++k) v[g * VPG + k] = (g * VPG + k < width) ? piece.t[k] : zero_of(T{});
+    for (int k = 0; k < VPG; ++k) v[g * VPG + k] = piece.t[k];
   }
 #pragma unroll
   for (int g = 0; g < WMAX / 8; ++g) {
     union { rlh_u32x4e u; unsigned short h[8]; } piece;
     piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(idx + well_idx_index(eoff, g * 8, tid)));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pos[g * 8 + k] = (g * 8 + k < width) ? (unsigned)piece.h[k] : 0u;
+    for (int k = 0; k < 8; ++k) pos[g * 8 + k] = (unsigned)piece.h[k];
   }
 }
 constexpr int kWellRows = 1024;
@@ -842,7 +843,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     for (int64_t r = r0; r < r1; ++r) w = std::max<int64_t>(w, indptr[r + 1] - indptr[r]);
     width[b] = (int32_t)std::min<int64_t>(w, 1 << 20);
     // groups per block: a multiple of 8 (one 16-byte load covers 2, 4 or -- bfloat16 -- 8 groups)
-    ngroups[b] = find_windows(indptr, indices, r0, r1, h->n_cols, 32, 8, wins[b]) / 64;
+    ngroups[b] = find_windows(indptr, indices, r0, r1, h->n_cols, 32, 64, 8, wins[b]) / 64;
   });
   int32_t wmax = 0, gmax = 0;
   int64_t staged = 0, slots = 0;
@@ -864,18 +865,18 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   int64_t goff = 0;
   for (int64_t b = 0; b < nblocks; ++b) {
     meta[b] = WellMeta{eoff, (int32_t)goff, width[b] | (ngroups[b] << 8)};
-    eoff += (width[b] + 7) / 8 * 8;                 // 16-byte pieces per thread: slots in multiples of 8
+    eoff += 8;                                      // every row is stored as 8 slots (16-byte pieces per thread)
     goff += ngroups[b];
   }
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
   std::vector<int32_t> gsrc((size_t)goff);
-  const int64_t epad = 8;                        // the kernel reads 8 slots whatever the block's width
+  const int64_t epad = 0;
   std::vector<uint16_t> idx((size_t)(eoff + epad) * kWellRows, 0);
   std::vector<T> vals((size_t)(eoff + epad) * kWellRows);
   memset(vals.data() + (size_t)eoff * kWellRows, 0, (size_t)epad * kWellRows * sizeof(T));
   parallel_blocks(nblocks, [&](int64_t b) {
     const std::vector<Win> &ws = wins[b];
-    fill_group_sources(ws, ngroups[b], gsrc.data() + meta[b].goff);
+    fill_group_sources(ws, ngroups[b], 64, gsrc.data() + meta[b].goff);
     const int64_t r0 = b * kWellRows;
     for (int l = 0; l < kWellRows; ++l) {
       const int64_t r = r0 + l;
@@ -883,7 +884,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
       // padding slots carry value 0 and the position of the row's own first entry, so that they
       // only ever touch a column the row references (0 * Inf of a foreign column would be NaN)
       const uint16_t padpos = len > 0 ? (uint16_t)staged_position(ws, indices[p]) : 0;
-      for (int32_t t = 0; t < (width[b] + 7) / 8 * 8; ++t) {
+      for (int32_t t = 0; t < 8; ++t) {
         const int64_t ev = well_val_index<T>(meta[b].eoff, t, l), ei = well_idx_index(meta[b].eoff, t, l);
         if (t < len) {
           idx[ei] = (uint16_t)staged_position(ws, indices[p + t]);

@@ -1,7 +1,7 @@
 // Host side of the 256-row interleaved windowed layout of the sparse operator (kernel: spmm_wide.inc).
 //
 // Rows are cut into blocks of 256 (one row per thread of a 256-thread workgroup).  Per block the
-// referenced columns are merged into windows of whole 64-column staging groups (spmm.h
+// referenced columns are merged into windows of whole 16-column staging groups (spmm.h
 // find_windows); an entry stores its value and the 16-bit position of its column in the block's
 // staged image.  Entries are stored in CHUNKS of 8 slots per row, as 16-byte pieces per thread:
 //   values    [chunk][piece k][row]   piece k = slots k * VPG .. + VPG - 1,  VPG = 16 / sizeof(T)
@@ -40,20 +40,20 @@ int wide_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const 
     int64_t w = 0;
     for (int64_t r = r0; r < r1; ++r) w = std::max<int64_t>(w, indptr[r + 1] - indptr[r]);
     width[b] = (int32_t)std::min<int64_t>(w, 1 << 20);
-    ngroups[b] = find_windows(indptr, indices, r0, r1, h->n_cols, 32, 1, wins[b]) / 64;
+    ngroups[b] = find_windows(indptr, indices, r0, r1, h->n_cols, 32, kWideGroup, 1, wins[b]) / kWideGroup;
   });
   int32_t wmax = 0, gmax = 0;
   int64_t staged = 0, slots = 0;
   for (int64_t b = 0; b < nblocks; ++b) {
     wmax = std::max(wmax, width[b]);
     gmax = std::max(gmax, ngroups[b]);
-    staged += (int64_t)ngroups[b] * 64;
+    staged += (int64_t)ngroups[b] * kWideGroup;
     slots += (int64_t)width[b] * kWideRows;
   }
   h->well_ratio = slots > 0 ? (double)staged / (double)slots : 0.0;
   // every block's image must fit the LDS with the smallest number of vectors per pass, positions
   // are 16 bits, a row has at most 8 * 32767 slots, and the group list must fit the header
-  if ((int64_t)gmax * 64 * wide_stride(wide_min_nv(h->dtype), es) + kWideHeader > kWideLdsBytes) return 0;
+  if ((int64_t)gmax * kWideGroup * wide_stride(wide_min_nv(h->dtype), es) + 2 * kWideHeader > kWideLdsBytes) return 0;
   if (gmax * 4 > kWideHeader || wmax > 8 * 32767) return 0;
   if (!force && staged * 10 > slots * 9) return 0;      // too little column locality for the staging to pay
   std::vector<WideMeta> meta((size_t)nblocks);
@@ -66,12 +66,12 @@ int wide_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const 
   }
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
   std::vector<int32_t> gsrc((size_t)goff);
-  const int64_t nchunks = eoff + 1;              // one chunk of padding: the kernel's prefetch runs one chunk ahead
+  const int64_t nchunks = eoff + kWidePadChunks;  // padding: the kernel's prefetch runs ahead of the last block's chunks
   std::vector<char> idx((size_t)nchunks * kWideRows * 16, 0);
   std::vector<char> vals((size_t)nchunks * VP * kWideRows * 16, 0);
   parallel_blocks(nblocks, [&](int64_t b) {
     const std::vector<Win> &ws = wins[b];
-    fill_group_sources(ws, ngroups[b], gsrc.data() + meta[b].goff);
+    fill_group_sources(ws, ngroups[b], kWideGroup, gsrc.data() + meta[b].goff);
     const int64_t r0 = b * kWideRows;
     for (int l = 0; l < kWideRows; ++l) {
       const int64_t r = r0 + l;
@@ -96,7 +96,7 @@ int wide_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const 
   h->well_inbounds = 1;
   h->well_aligned = 1;
   for (int64_t g = 0; g < goff; ++g) {
-    if ((int64_t)gsrc[g] + 64 > h->n_cols) h->well_inbounds = 0;
+    if ((int64_t)gsrc[g] + kWideGroup > h->n_cols) h->well_inbounds = 0;
     if (gsrc[g] & 7) h->well_aligned = 0;
   }
   well_schedule(wins, nblocks, n, kWideRows, ctx().num_cu * 2, h->wide_order);

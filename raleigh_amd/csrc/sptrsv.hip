@@ -1,0 +1,584 @@
+// Incomplete LU preconditioner on the device: host ILUT factorisation + level-scheduled
+// sparse triangular solves on the whole n x m block.
+//
+// Reference: raleigh/algebra/sparse_mkl.py:122-140 (IncompleteLU) -> raleigh/algebra/mkl_wrap.py:279-347:
+// mkl dcsrilut(tol, maxfil) once, then per VECTOR two mkl_dcsrtrsv calls on the host.  Here
+//  * rlh_ilut_factor restates the dual-threshold ILUT(p, tau) of Saad that dcsrilut implements (drop
+//    entries below tau * ||row||_2, keep at most p = maxfil largest entries in the L and in the U
+//    part of every row) on the host, in double / complex double;
+//  * rlh_sptrsv_create turns a triangular CSR factor into a device operator: rows are grouped into
+//    dependency LEVELS (a row's level is one more than the largest level among the rows it
+//    references), the rows of a level are independent;
+//  * rlh_sptrsv_solve_chain applies a chain of such operators to a block of m vectors at once: the
+//    block is transposed into a row-major scratch [row][vector] (the m values of a row are then
+//    one contiguous run: a gather of a referenced row is one or two cache lines that are used in
+//    full), one small kernel per level -- LPR lanes per row, each lane owning a 16-byte piece of the
+//    row (a run of consecutive small levels shares ONE launch: a single 1024-thread workgroup walks
+//    them behind workgroup barriers) -- and transposed back.  The launches of one chain are captured
+//    into a hipGraph and replayed (the launch overhead, not the arithmetic, bounds it).
+#include <math.h>
+
+#include <algorithm>
+#include <complex>
+#include <queue>
+#include <vector>
+
+#include "common.h"
+
+struct rlh_factors {
+  int dtype;                       // RLH_D or RLH_Z
+  int64_t n;
+  std::vector<int64_t> lptr, uptr;
+  std::vector<int32_t> lidx, uidx;
+  std::vector<char> lval, uval;    // L strictly lower (unit diagonal implied), U upper incl. diagonal
+};
+
+struct rlh_sptrsv {
+  int dtype;
+  int64_t n, nnz;                  // nnz: stored off-diagonal entries
+  int lower, unit;
+  int64_t *rowptr;                 // device, n + 1
+  int32_t *cols;                   // device
+  void *vals;                      // device
+  void *dinv;                      // device: 1 / diagonal (nullptr: unit diagonal)
+  int32_t *lev_rows;               // device: the rows ordered by level
+  std::vector<int64_t> lev_off;    // host: first position of every level in lev_rows, nlevels + 1
+  int64_t *lev_off_d;              // device copy (the chain kernel walks several levels per launch)
+  int64_t device_bytes;
+  // scratch and captured launch sequence of the chain this operator heads
+  void *work;
+  int64_t work_bytes;
+  hipGraphExec_t graph;
+  uint64_t graph_key;
+};
+
+namespace rlh {
+
+// ------------------------------------------------------------------ host ILUT
+static inline double mag(double v) { return fabs(v); }
+static inline double mag(const std::complex<double> &v) { return std::abs(v); }
+
+template <typename S>
+static int ilut_factor(int64_t n, const int64_t *indptr, const int32_t *indices, const S *values, double tol,
+                       int64_t maxfil, rlh_factors *f) {
+  f->n = n;
+  f->lptr.assign((size_t)n + 1, 0);
+  f->uptr.assign((size_t)n + 1, 0);
+  std::vector<S> lval, uval;
+  std::vector<int32_t> &lidx = f->lidx, &uidx = f->uidx;
+  std::vector<S> w((size_t)n);
+  std::vector<int64_t> mark((size_t)n, -1);
+  std::vector<int64_t> udiag_pos((size_t)n, 0);        // position of u_kk in uval
+  std::vector<int32_t> lcand, ucand;
+  std::vector<std::pair<double, int32_t>> keep;
+  for (int64_t i = 0; i < n; ++i) {
+    double nrm = 0.0;
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) nrm += mag(values[e]) * mag(values[e]);
+    nrm = sqrt(nrm);
+    RLH_REQUIRE(nrm > 0.0, "rlh_ilut_factor: row %lld is empty", (long long)i);
+    const double tau = tol * nrm;
+    std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> heap;   // columns < i still to eliminate
+    ucand.clear();
+    lcand.clear();
+    mark[i] = i;
+    w[i] = S(0);
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+      const int32_t j = indices[e];
+      if (mark[j] != i || j == i) {
+        if (mark[j] != i) { mark[j] = i; w[j] = S(0); }
+        if (j < i) heap.push(j); else if (j > i) ucand.push_back(j);
+      }
+      w[j] += values[e];
+    }
+    // (duplicate column indices in a row were summed above; a duplicate may have been pushed twice)
+    int32_t last = -1;
+    while (!heap.empty()) {
+      const int32_t k = heap.top();
+      heap.pop();
+      if (k == last) continue;
+      last = k;
+      const S lik = w[k] / uval[(size_t)udiag_pos[k]];
+      if (mag(lik) < tau) continue;                       // first dropping rule
+      w[k] = lik;
+      lcand.push_back(k);
+      for (int64_t e = udiag_pos[k] + 1; e < f->uptr[k + 1]; ++e) {      // row k of U beyond its diagonal
+        const int32_t j = uidx[(size_t)e];
+        if (mark[j] != i) {
+          mark[j] = i;
+          w[j] = S(0);
+          if (j < i) heap.push(j); else ucand.push_back(j);
+        }
+        w[j] -= lik * uval[(size_t)e];
+      }
+    }
+    // second dropping rule: the p largest of each part (all of them already >= tau in L)
+    auto select = [&](std::vector<int32_t> &cand, bool threshold) {
+      keep.clear();
+      for (int32_t j : cand) {
+        const double a = mag(w[j]);
+        if (!threshold || a >= tau) keep.push_back({a, j});
+      }
+      if ((int64_t)keep.size() > maxfil) {
+        std::nth_element(keep.begin(), keep.begin() + maxfil, keep.end(),
+                         [](const std::pair<double, int32_t> &x, const std::pair<double, int32_t> &y) {
+                           return x.first > y.first || (x.first == y.first && x.second < y.second);
+                         });
+        keep.resize((size_t)maxfil);
+      }
+      cand.clear();
+      for (auto &kv : keep) cand.push_back(kv.second);
+      std::sort(cand.begin(), cand.end());
+    };
+    select(lcand, false);
+    std::sort(ucand.begin(), ucand.end());
+    ucand.erase(std::unique(ucand.begin(), ucand.end()), ucand.end());
+    select(ucand, true);
+    for (int32_t j : lcand) { lidx.push_back(j); lval.push_back(w[j]); }
+    f->lptr[i + 1] = (int64_t)lidx.size();
+    S d = w[i];
+    if (mag(d) < tau || mag(d) == 0.0) d = S(tau > 0.0 ? tau : 1e-4 * nrm);   // small pivot: replaced, as dcsrilut does
+    udiag_pos[i] = (int64_t)uidx.size();
+    uidx.push_back((int32_t)i);
+    uval.push_back(d);
+    for (int32_t j : ucand) { uidx.push_back(j); uval.push_back(w[j]); }
+    f->uptr[i + 1] = (int64_t)uidx.size();
+  }
+  f->lval.assign((const char *)lval.data(), (const char *)(lval.data() + lval.size()));
+  f->uval.assign((const char *)uval.data(), (const char *)(uval.data() + uval.size()));
+  return 0;
+}
+
+// ------------------------------------------------------------------ device kernels
+template <typename T, int EPL> struct alignas(16) Piece { T e[EPL]; };
+
+// W[r][v] = B[perm ? perm[r] : r, v] (row-major scratch, leading dimension ldw, columns >= m zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_transpose_in(const T *__restrict__ B, int64_t ldb, const int64_t *__restrict__ perm,
+                                                         T *__restrict__ W, int ldw, int64_t n, int m) {
+  constexpr int EPL = 16 / (int)sizeof(T);
+  const int ppr = ldw / EPL;                               // 16-byte pieces per row
+  const int64_t total = n * ppr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / ppr;
+    const int p = (int)(t - r * ppr);
+    const int64_t src = perm ? perm[r] : r;
+    Piece<T, EPL> out;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int v = p * EPL + e;
+      out.e[e] = v < m ? B[src + (int64_t)v * ldb] : zero_of(T{});
+    }
+    *reinterpret_cast<Piece<T, EPL> *>(W + r * ldw + p * EPL) = out;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_transpose_out(const T *__restrict__ W, int ldw, const int64_t *__restrict__ perm,
+                                                          T *__restrict__ X, int64_t ldx, int64_t n, int m) {
+  constexpr int EPL = 16 / (int)sizeof(T);
+  const int ppr = ldw / EPL;
+  const int64_t total = n * ppr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / ppr;
+    const int p = (int)(t - r * ppr);
+    const int64_t dst = perm ? perm[r] : r;
+    const Piece<T, EPL> in = *reinterpret_cast<const Piece<T, EPL> *>(W + r * ldw + p * EPL);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int v = p * EPL + e;
+      if (v < m) X[dst + (int64_t)v * ldx] = in.e[e];
+    }
+  }
+}
+
+__device__ __forceinline__ float  neg_of(float a)  { return -a; }
+__device__ __forceinline__ double neg_of(double a) { return -a; }
+__device__ __forceinline__ c32 neg_of(c32 a) { return c32{-a.re, -a.im}; }
+__device__ __forceinline__ c64 neg_of(c64 a) { return c64{-a.re, -a.im}; }
+
+// One row of one level for the 16-byte piece(s) of lane `lane` of the row's LPR lanes:
+// W[r][:] = (W[r][:] - sum_e vals[e] W[cols[e]][:]) * dinv[r].
+template <typename T, int LPR>
+__device__ __forceinline__ void trsv_row(int64_t r, int lane, const int64_t *__restrict__ rowptr,
+                                         const int32_t *__restrict__ cols, const T *__restrict__ vals,
+                                         const T *__restrict__ dinv, T *W, int ldw, int ppr) {
+  constexpr int EPL = 16 / (int)sizeof(T);
+  using P = Piece<T, EPL>;
+  for (int p = lane; p < ppr; p += LPR) {                  // (one trip unless the block has more than 64 pieces per row)
+    T *wr = W + r * ldw + p * EPL;
+    P acc = *reinterpret_cast<const P *>(wr);
+    const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
+    for (int64_t e = e0; e < e1; e += 4) {
+      int32_t c[4];
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ee = e + u < e1 ? e + u : e1 - 1;    // surplus slots repeat the last entry with value 0
+        c[u] = cols[ee];
+        v[u] = e + u < e1 ? neg_of(vals[ee]) : zero_of(T{});
+      }
+      P x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const P *>(W + (int64_t)c[u] * ldw + p * EPL);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) fma_acc(acc.e[k], v[u], x[u].e[k]);
+    }
+    if (dinv) {
+      const T d = dinv[r];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) acc.e[k] = mul_of(acc.e[k], d);
+    }
+    *reinterpret_cast<P *>(wr) = acc;
+  }
+}
+
+// One large dependency level: LPR lanes per row over as many workgroups as the level fills.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void trsv_level_kernel(const int32_t *__restrict__ rows, int nrows,
+                                                         const int64_t *__restrict__ rowptr, const int32_t *__restrict__ cols,
+                                                         const T *__restrict__ vals, const T *__restrict__ dinv,
+                                                         T *W, int ldw, int ppr) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t rloc = gid / LPR;
+  if (rloc >= nrows) return;
+  trsv_row<T, LPR>(rows[rloc], (int)(gid % LPR), rowptr, cols, vals, dinv, W, ldw, ppr);
+}
+
+// A run of SMALL consecutive levels [l0, l1) in ONE workgroup of 1024 threads: the levels follow each
+// other behind a workgroup barrier (the rows a level reads were written by waves of the same
+// workgroup: workgroup-scope release / acquire is what __syncthreads() provides), so a long chain of
+// tiny levels -- an FE matrix in a banded ordering has thousands of levels of a few dozen rows --
+// costs one launch instead of one launch per level.
+template <typename T, int LPR>
+__global__ __launch_bounds__(1024) void trsv_chain_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ lev_off,
+                                                          int l0, int l1, const int64_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ cols, const T *__restrict__ vals,
+                                                          const T *__restrict__ dinv, T *W, int ldw, int ppr) {
+  const int tid = threadIdx.x;
+  int64_t r0 = lev_off[l0];
+  for (int lev = l0; lev < l1; ++lev) {
+    const int64_t r1 = lev_off[lev + 1];
+    const int64_t tasks = (r1 - r0) * LPR;
+    for (int64_t t = tid; t < tasks; t += 1024)
+      trsv_row<T, LPR>(rows[r0 + t / LPR], (int)(t % LPR), rowptr, cols, vals, dinv, W, ldw, ppr);
+    __syncthreads();
+    r0 = r1;
+  }
+}
+
+constexpr int64_t kChainTasks = 4096;      // a level of at most this many (row, lane) tasks counts as small
+
+template <typename T, int LPR>
+static void launch_levels_lpr(hipStream_t s, const rlh_sptrsv *t, T *W, int ldw, int ppr) {
+  const int64_t nl = (int64_t)t->lev_off.size() - 1;
+  int64_t lev = 0;
+  while (lev < nl) {
+    const int64_t nrows = t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev];
+    if (nrows * LPR > kChainTasks) {
+      const int64_t threads = nrows * LPR;
+      hipLaunchKernelGGL((trsv_level_kernel<T, LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                         t->lev_rows + t->lev_off[(size_t)lev], (int)nrows, t->rowptr, t->cols, (const T *)t->vals,
+                         (const T *)t->dinv, W, ldw, ppr);
+      ++lev;
+      continue;
+    }
+    int64_t end = lev + 1;                    // the run of small levels starting here
+    while (end < nl && (t->lev_off[(size_t)end + 1] - t->lev_off[(size_t)end]) * LPR <= kChainTasks) ++end;
+    hipLaunchKernelGGL((trsv_chain_kernel<T, LPR>), dim3(1), dim3(1024), 0, s, t->lev_rows, t->lev_off_d, (int)lev, (int)end,
+                       t->rowptr, t->cols, (const T *)t->vals, (const T *)t->dinv, W, ldw, ppr);
+    lev = end;
+  }
+}
+
+template <typename T>
+static void launch_levels(hipStream_t s, const rlh_sptrsv *t, T *W, int ldw, int ppr) {
+  int lpr = 1;
+  while (lpr < ppr && lpr < 64) lpr *= 2;
+  switch (lpr) {
+    case 1: launch_levels_lpr<T, 1>(s, t, W, ldw, ppr); break;
+    case 2: launch_levels_lpr<T, 2>(s, t, W, ldw, ppr); break;
+    case 4: launch_levels_lpr<T, 4>(s, t, W, ldw, ppr); break;
+    case 8: launch_levels_lpr<T, 8>(s, t, W, ldw, ppr); break;
+    case 16: launch_levels_lpr<T, 16>(s, t, W, ldw, ppr); break;
+    case 32: launch_levels_lpr<T, 32>(s, t, W, ldw, ppr); break;
+    default: launch_levels_lpr<T, 64>(s, t, W, ldw, ppr); break;
+  }
+}
+
+// number of kernel launches launch_levels issues for an operator
+static int64_t count_launches(const rlh_sptrsv *t, int lpr) {
+  const int64_t nl = (int64_t)t->lev_off.size() - 1;
+  int64_t n = 0, lev = 0;
+  while (lev < nl) {
+    ++n;
+    if ((t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr > kChainTasks) { ++lev; continue; }
+    ++lev;
+    while (lev < nl && (t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr <= kChainTasks) ++lev;
+  }
+  return n;
+}
+
+template <int DT>
+static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *perm_in, const int64_t *perm_out, int64_t m,
+                            const void *B_, int64_t ldb, void *X_, int64_t ldx) {
+  using T = typename DType<DT>::T;
+  constexpr int EPL = 16 / (int)sizeof(T);
+  Context &c = ctx();
+  rlh_sptrsv *head = ops[0];
+  const int64_t n = head->n;
+  const int ppr = (int)((m + EPL - 1) / EPL);
+  const int ldw = ppr * EPL;
+  const int64_t need = n * ldw * (int64_t)sizeof(T);
+  if (head->work_bytes < need) {
+    RLH_HIP(hipStreamSynchronize(c.stream));
+    if (head->work) RLH_HIP(hipFree(head->work));
+    head->work = nullptr; head->work_bytes = 0;
+    if (head->graph) { (void)hipGraphExecDestroy(head->graph); head->graph = nullptr; }
+    RLH_HIP(hipMalloc(&head->work, (size_t)need));
+    head->work_bytes = need;
+  }
+  T *W = (T *)head->work;
+  int64_t nb = (n * ppr + 255) / 256;
+  if (nb > (int64_t)c.num_cu * 16) nb = (int64_t)c.num_cu * 16;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((trsv_transpose_in<T>), dim3((unsigned)nb), dim3(256), 0, c.stream, (const T *)B_, ldb, perm_in, W, ldw, n,
+                     (int)m);
+  RLH_HIP(hipGetLastError());
+  // the level launches depend only on (operators, m, scratch): captured once, replayed afterwards
+  uint64_t key = (uint64_t)m * 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < nops; ++i) key = (key ^ (uint64_t)(uintptr_t)ops[i]) * 0xBF58476D1CE4E5B9ull;
+  key ^= (uint64_t)(uintptr_t)c.stream;
+  int64_t launches = 0;
+  {
+    int lpr = 1;
+    while (lpr < ppr && lpr < 64) lpr *= 2;
+    for (int i = 0; i < nops; ++i) launches += count_launches(ops[i], lpr);
+  }
+  const bool use_graph = launches >= 8 && !getenv("RLH_SPTRSV_NO_GRAPH");
+  if (use_graph) {
+    if (!head->graph || head->graph_key != key) {
+      if (head->graph) { (void)hipGraphExecDestroy(head->graph); head->graph = nullptr; }
+      hipGraph_t g = nullptr;
+      RLH_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < nops; ++i) launch_levels<T>(c.stream, ops[i], W, ldw, ppr);
+      RLH_HIP(hipStreamEndCapture(c.stream, &g));
+      RLH_HIP(hipGraphInstantiate(&head->graph, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      head->graph_key = key;
+    }
+    RLH_HIP(hipGraphLaunch(head->graph, c.stream));
+  } else {
+    for (int i = 0; i < nops; ++i) launch_levels<T>(c.stream, ops[i], W, ldw, ppr);
+    RLH_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL((trsv_transpose_out<T>), dim3((unsigned)nb), dim3(256), 0, c.stream, (const T *)W, ldw, perm_out, (T *)X_, ldx,
+                     n, (int)m);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int DT>
+static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *indices, const void *values_) {
+  using T = typename DType<DT>::T;
+  const T *values = (const T *)values_;
+  const int64_t n = t->n;
+  std::vector<int64_t> rp((size_t)n + 1, 0);
+  std::vector<int32_t> cols;
+  std::vector<T> vals, dinv;
+  if (!t->unit) dinv.resize((size_t)n);
+  std::vector<int32_t> level((size_t)n, 0);
+  cols.reserve((size_t)(indptr[n] - indptr[0]));
+  vals.reserve((size_t)(indptr[n] - indptr[0]));
+  for (int64_t i = 0; i < n; ++i) {
+    bool have_diag = false;
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+      const int32_t j = indices[e];
+      RLH_REQUIRE(j >= 0 && j < n, "rlh_sptrsv_create: column index out of range in row %lld", (long long)i);
+      if (j == i) {
+        RLH_REQUIRE(!t->unit, "rlh_sptrsv_create: a unit-diagonal factor must not store its diagonal (row %lld)", (long long)i);
+        const T d = values[e];
+        double re, im;
+        if constexpr (DType<DT>::cplx) { re = d.re; im = d.im; } else { re = d; im = 0.0; }
+        const double a2 = re * re + im * im;
+        RLH_REQUIRE(a2 > 0.0, "rlh_sptrsv_create: zero diagonal in row %lld", (long long)i);
+        if constexpr (DType<DT>::cplx) dinv[(size_t)i] = T{(decltype(d.re))(re / a2), (decltype(d.re))(-im / a2)};
+        else dinv[(size_t)i] = (T)(1.0 / re);
+        have_diag = true;
+      } else {
+        RLH_REQUIRE(t->lower ? j < i : j > i, "rlh_sptrsv_create: entry (%lld, %d) lies in the wrong triangle", (long long)i, j);
+        cols.push_back(j);
+        vals.push_back(values[e]);
+      }
+    }
+    RLH_REQUIRE(t->unit || have_diag, "rlh_sptrsv_create: row %lld has no diagonal entry", (long long)i);
+    rp[(size_t)i + 1] = (int64_t)cols.size();
+  }
+  // dependency levels
+  int32_t nlev = 0;
+  if (t->lower) {
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t l = 0;
+      for (int64_t e = rp[i]; e < rp[i + 1]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
+      level[(size_t)i] = l;
+      nlev = std::max(nlev, l + 1);
+    }
+  } else {
+    for (int64_t i = n - 1; i >= 0; --i) {
+      int32_t l = 0;
+      for (int64_t e = rp[i]; e < rp[i + 1]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
+      level[(size_t)i] = l;
+      nlev = std::max(nlev, l + 1);
+    }
+  }
+  t->lev_off.assign((size_t)nlev + 1, 0);
+  for (int64_t i = 0; i < n; ++i) t->lev_off[(size_t)level[(size_t)i] + 1]++;
+  for (int32_t l = 0; l < nlev; ++l) t->lev_off[(size_t)l + 1] += t->lev_off[(size_t)l];
+  std::vector<int32_t> order((size_t)n);
+  {
+    std::vector<int64_t> next(t->lev_off.begin(), t->lev_off.end() - 1);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)next[(size_t)level[(size_t)i]]++] = (int32_t)i;   // ascending rows inside a level
+  }
+  t->nnz = (int64_t)cols.size();
+  RLH_HIP(hipMalloc((void **)&t->rowptr, (size_t)(n + 1) * sizeof(int64_t)));
+  RLH_HIP(hipMemcpy(t->rowptr, rp.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  RLH_HIP(hipMalloc((void **)&t->cols, std::max<size_t>(cols.size(), 1) * sizeof(int32_t)));
+  RLH_HIP(hipMalloc((void **)&t->vals, std::max<size_t>(vals.size(), 1) * sizeof(T)));
+  if (!cols.empty()) {
+    RLH_HIP(hipMemcpy(t->cols, cols.data(), cols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    RLH_HIP(hipMemcpy(t->vals, vals.data(), vals.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  if (!t->unit) {
+    RLH_HIP(hipMalloc((void **)&t->dinv, (size_t)n * sizeof(T)));
+    RLH_HIP(hipMemcpy(t->dinv, dinv.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  RLH_HIP(hipMalloc((void **)&t->lev_off_d, t->lev_off.size() * sizeof(int64_t)));
+  RLH_HIP(hipMemcpy(t->lev_off_d, t->lev_off.data(), t->lev_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  RLH_HIP(hipMalloc((void **)&t->lev_rows, std::max<size_t>((size_t)n, 1) * sizeof(int32_t)));
+  if (n > 0) RLH_HIP(hipMemcpy(t->lev_rows, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  t->device_bytes = (n + 1) * 8 + (int64_t)cols.size() * (4 + (int64_t)sizeof(T)) + n * 4 + (t->unit ? 0 : n * (int64_t)sizeof(T));
+  return 0;
+}
+
+}  // namespace rlh
+
+using namespace rlh;
+
+extern "C" {
+
+int rlh_ilut_factor(rlh_factors_t *out, int dtype, int64_t n, const int64_t *indptr, const int32_t *indices,
+                    const void *values, double tol, int64_t maxfil) {
+  RLH_REQUIRE(out != nullptr, "rlh_ilut_factor: null handle pointer");
+  *out = nullptr;
+  RLH_REQUIRE(dtype == RLH_D || dtype == RLH_Z, "rlh_ilut_factor: the factorisation runs in double / complex double");
+  RLH_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && indptr && (indptr[n] == 0 || (indices && values)), "rlh_ilut_factor: bad matrix");
+  RLH_REQUIRE(tol >= 0.0 && maxfil >= 0, "rlh_ilut_factor: tol and maxfil must not be negative");
+  for (int64_t i = 0; i < n; ++i) {
+    RLH_REQUIRE(indptr[i + 1] >= indptr[i], "rlh_ilut_factor: indptr decreases at row %lld", (long long)i);
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e)
+      RLH_REQUIRE(indices[e] >= 0 && indices[e] < n, "rlh_ilut_factor: column index out of range in row %lld", (long long)i);
+  }
+  rlh_factors *f = new rlh_factors();
+  f->dtype = dtype;
+  int rc = dtype == RLH_D ? ilut_factor<double>(n, indptr, indices, (const double *)values, tol, maxfil, f)
+                          : ilut_factor<std::complex<double>>(n, indptr, indices, (const std::complex<double> *)values, tol, maxfil, f);
+  if (rc) { delete f; return rc; }
+  *out = f;
+  return 0;
+}
+
+int rlh_factors_nnz(rlh_factors_t f, int64_t *nnz_l, int64_t *nnz_u) {
+  RLH_REQUIRE(f != nullptr, "rlh_factors_nnz: null handle");
+  if (nnz_l) *nnz_l = (int64_t)f->lidx.size();
+  if (nnz_u) *nnz_u = (int64_t)f->uidx.size();
+  return 0;
+}
+
+int rlh_factors_get(rlh_factors_t f, int which, int64_t *indptr, int32_t *indices, void *values) {
+  RLH_REQUIRE(f != nullptr && (which == 0 || which == 1), "rlh_factors_get: bad arguments");
+  const std::vector<int64_t> &p = which ? f->uptr : f->lptr;
+  const std::vector<int32_t> &i = which ? f->uidx : f->lidx;
+  const std::vector<char> &v = which ? f->uval : f->lval;
+  if (indptr) memcpy(indptr, p.data(), p.size() * sizeof(int64_t));
+  if (indices && !i.empty()) memcpy(indices, i.data(), i.size() * sizeof(int32_t));
+  if (values && !v.empty()) memcpy(values, v.data(), v.size());
+  return 0;
+}
+
+int rlh_factors_destroy(rlh_factors_t f) {
+  delete f;
+  return 0;
+}
+
+int rlh_sptrsv_create(rlh_sptrsv_t *out, int dtype, int64_t n, const int64_t *indptr, const int32_t *indices,
+                      const void *values, int lower, int unit_diag) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(out != nullptr, "rlh_sptrsv_create: null handle pointer");
+  *out = nullptr;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_sptrsv_create: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && indptr && indptr[0] == 0, "rlh_sptrsv_create: bad matrix");
+  RLH_REQUIRE(indptr[n] == 0 || (indices && values), "rlh_sptrsv_create: null indices/values");
+  rlh_sptrsv *t = new rlh_sptrsv();
+  t->dtype = dtype; t->n = n; t->nnz = 0; t->lower = lower ? 1 : 0; t->unit = unit_diag ? 1 : 0;
+  t->rowptr = nullptr; t->cols = nullptr; t->vals = nullptr; t->dinv = nullptr; t->lev_rows = nullptr; t->lev_off_d = nullptr;
+  t->device_bytes = 0; t->work = nullptr; t->work_bytes = 0; t->graph = nullptr; t->graph_key = 0;
+  int rc = 1;
+  switch (dtype) {
+    case RLH_S: rc = sptrsv_build<RLH_S>(t, indptr, indices, values); break;
+    case RLH_D: rc = sptrsv_build<RLH_D>(t, indptr, indices, values); break;
+    case RLH_C: rc = sptrsv_build<RLH_C>(t, indptr, indices, values); break;
+    case RLH_Z: rc = sptrsv_build<RLH_Z>(t, indptr, indices, values); break;
+  }
+  if (rc) { rlh_sptrsv_destroy(t); return rc; }
+  *out = t;
+  return 0;
+}
+
+int rlh_sptrsv_info(rlh_sptrsv_t t, int64_t *nnz, int64_t *levels, int64_t *device_bytes) {
+  RLH_REQUIRE(t != nullptr, "rlh_sptrsv_info: null handle");
+  if (nnz) *nnz = t->nnz;
+  if (levels) *levels = (int64_t)t->lev_off.size() - 1;
+  if (device_bytes) *device_bytes = t->device_bytes;
+  return 0;
+}
+
+int rlh_sptrsv_solve_chain(int nops, const rlh_sptrsv_t *ops, const int64_t *d_perm_in, const int64_t *d_perm_out,
+                           int64_t m, const void *B, int64_t ldb, void *X, int64_t ldx) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(nops >= 1 && nops <= 8 && ops != nullptr, "rlh_sptrsv_solve_chain: 1 to 8 operators");
+  for (int i = 0; i < nops; ++i)
+    RLH_REQUIRE(ops[i] != nullptr && ops[i]->dtype == ops[0]->dtype && ops[i]->n == ops[0]->n,
+                "rlh_sptrsv_solve_chain: the operators must have one type and one size");
+  RLH_REQUIRE(m >= 0 && m <= 65536, "rlh_sptrsv_solve_chain: bad block size");
+  if (m == 0 || ops[0]->n == 0) return 0;
+  RLH_REQUIRE(B && X && ldb >= ops[0]->n && ldx >= ops[0]->n, "rlh_sptrsv_solve_chain: bad block arguments");
+  switch (ops[0]->dtype) {
+    case RLH_S: return solve_chain_impl<RLH_S>(nops, ops, d_perm_in, d_perm_out, m, B, ldb, X, ldx);
+    case RLH_D: return solve_chain_impl<RLH_D>(nops, ops, d_perm_in, d_perm_out, m, B, ldb, X, ldx);
+    case RLH_C: return solve_chain_impl<RLH_C>(nops, ops, d_perm_in, d_perm_out, m, B, ldb, X, ldx);
+    case RLH_Z: return solve_chain_impl<RLH_Z>(nops, ops, d_perm_in, d_perm_out, m, B, ldb, X, ldx);
+  }
+  return 1;
+}
+
+int rlh_sptrsv_destroy(rlh_sptrsv_t t) {
+  if (!t) return 0;
+  if (ctx().ready) {
+    (void)hipStreamSynchronize(ctx().stream);
+    if (t->graph) (void)hipGraphExecDestroy(t->graph);
+    if (t->rowptr) (void)hipFree(t->rowptr);
+    if (t->cols) (void)hipFree(t->cols);
+    if (t->vals) (void)hipFree(t->vals);
+    if (t->dinv) (void)hipFree(t->dinv);
+    if (t->lev_rows) (void)hipFree(t->lev_rows);
+    if (t->lev_off_d) (void)hipFree(t->lev_off_d);
+    if (t->work) (void)hipFree(t->work);
+  }
+  delete t;
+  return 0;
+}
+
+}  // extern "C"

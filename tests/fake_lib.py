@@ -115,7 +115,12 @@ class FakeLib:
 
     rlh_d2h = rlh_h2d
     rlh_d2d = rlh_h2d
-    rlh_fetch = rlh_h2d
+
+    def rlh_fetch(self, h, d, nbytes):
+        self._count('fetch')
+        self._count('sync')
+        ctypes.memmove(_addr(h), _addr(d), int(nbytes))
+        return 0
 
     def rlh_copy2d(self, dst, dpitch, src, spitch, width, rows, kind):
         d, s = _addr(dst), _addr(src)
@@ -134,6 +139,22 @@ class FakeLib:
         for out in (d_out, h_out):
             if _addr(out):
                 _flat(out, _DT[code], my * mx)[:] = g.ravel()
+        if _addr(h_out):
+            self._count('sync')
+        return 0
+
+    def rlh_gram_multi(self, code, n, nx, X, ldx, mx, ny, Y, ldy, my, d_out, h_out):
+        self._count('gram_multi')
+        lx, mxs = _flat(ldx, np.int64, nx), _flat(mx, np.int64, nx)
+        ly, mys = _flat(ldy, np.int64, ny), _flat(my, np.int64, ny)
+        xs = np.concatenate([_block(X[k], code, n, int(mxs[k]), int(lx[k])) for k in range(nx)], axis=0)
+        ys = np.concatenate([_block(Y[k], code, n, int(mys[k]), int(ly[k])) for k in range(ny)], axis=0)
+        g = ops.gram(xs, ys).astype(_DT[code])
+        for out in (d_out, h_out):
+            if _addr(out):
+                _flat(out, _DT[code], g.size)[:] = g.ravel()
+        if _addr(h_out):
+            self._count('sync')
         return 0
 
     def rlh_dots(self, code, n, m, X, ldx, Y, ldy, d_out, h_out):
@@ -144,6 +165,8 @@ class FakeLib:
         for out in (d_out, h_out):
             if _addr(out):
                 _flat(out, _DT[code], m)[:] = v
+        if _addr(h_out):
+            self._count('sync')
         return 0
 
     def rlh_dots_transp(self, code, n, m, X, ldx, Y, ldy, d_out):
@@ -304,6 +327,79 @@ class FakeLib:
         self._next_handle += 1
         self._csr[h] = _Csr(sp.csr_matrix((va, ix, ip), shape=(n_rows, n_cols)), code)
         ph._obj.value = h
+        return 0
+
+    # ---- ILUT (host-only entry points of the real library) and triangular chains (SciPy)
+    def _real(self):
+        import os
+        from raleigh_amd import _lib
+        if not hasattr(self, '_dll'):
+            self._dll = _lib._load()
+        return self._dll
+
+    def rlh_ilut_factor(self, *a):
+        rc = self._real().rlh_ilut_factor(*a)
+        if rc:
+            self._err = self._real().rlh_last_error()
+        return rc
+
+    def rlh_factors_nnz(self, *a):
+        return self._real().rlh_factors_nnz(*a)
+
+    def rlh_factors_get(self, *a):
+        return self._real().rlh_factors_get(*a)
+
+    def rlh_factors_destroy(self, *a):
+        return self._real().rlh_factors_destroy(*a)
+
+    def rlh_sptrsv_create(self, ph, code, n, indptr, indices, values, lower, unit):
+        ip = _flat(indptr, np.int64, n + 1).copy()
+        nnz = int(ip[-1])
+        ix = _flat(indices, np.int32, nnz).copy()
+        va = _flat(values, _DT[code], nnz).copy()
+        mat = sp.csr_matrix((va, ix, ip), shape=(n, n))
+        rows = np.repeat(np.arange(n), np.diff(ip))
+        if unit and np.any(rows == ix):
+            return self._fail('rlh_sptrsv_create: a unit-diagonal factor must not store its diagonal')
+        if np.any((ix > rows) if lower else (ix < rows)):
+            return self._fail('rlh_sptrsv_create: entry lies in the wrong triangle')
+        if unit:
+            mat = mat + sp.identity(n, dtype=_DT[code], format='csr')
+        elif np.any(mat.diagonal() == 0):
+            return self._fail('rlh_sptrsv_create: zero diagonal')
+        h = self._next_handle
+        self._next_handle += 1
+        self._csr[h] = (sp.csr_matrix(mat), bool(lower), code, nnz - (0 if unit else n))
+        ph._obj.value = h
+        return 0
+
+    def rlh_sptrsv_info(self, h, nnz, levels, nbytes):
+        ctypes.cast(nnz, ctypes.POINTER(ctypes.c_int64))[0] = self._csr[_addr(h)][3]
+        ctypes.cast(levels, ctypes.POINTER(ctypes.c_int64))[0] = 1
+        ctypes.cast(nbytes, ctypes.POINTER(ctypes.c_int64))[0] = 0
+        return 0
+
+    def rlh_sptrsv_solve_chain(self, nops, ops, perm_in, perm_out, m, B, ldb, X, ldx):
+        import scipy.sparse.linalg as sla
+        self._count('rlh_sptrsv_solve_chain')
+        handles = [int(ops[i]) for i in range(nops)]
+        mat0, _, code, _ = self._csr[handles[0]]
+        n = mat0.shape[0]
+        w = _block(B, code, n, m, ldb).T.copy()
+        if _addr(perm_in):
+            w = w[_flat(perm_in, np.int64, n)]
+        for hh in handles:
+            mat, lower, _, _ = self._csr[hh]
+            w = sla.spsolve_triangular(mat, w, lower=lower)
+        out = _block(X, code, n, m, ldx)
+        if _addr(perm_out):
+            out[:, _flat(perm_out, np.int64, n)] = w.T
+        else:
+            out[:, :] = w.T
+        return 0
+
+    def rlh_sptrsv_destroy(self, h):
+        self._csr.pop(_addr(h), None)
         return 0
 
     def rlh_csr_destroy(self, h):

@@ -353,3 +353,57 @@ def test_jacobi_sweep_ilu_preconditioner():
         assert np.max(np.abs(lmd[:4] - ana) / ana) < 1e-10
         its[name] = partial_hevp.last['iterations']
     assert its['ilu'] * 1.5 < its['none']
+
+
+def test_host_round_trips_per_iteration(fake, monkeypatch):
+    """Fused Gram pairs and batched reductions: in the steady state -- before the
+    first pair is locked -- the driver synchronises with the device five times per iteration (Ritz-pair
+    check + residual norms; conjugation coefficients; projection on X; Gram of (X, Y); A-Gram of
+    (X, Y)) where the reference's call sequence makes 13 blocking calls (raleigh/core/solver.py:854-861,
+    968-974, 1321-1339, 1360, 1376-1381, 1444-1447), and the results do not change."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip import Vectors
+    from oracle.sparse import lap3d
+    A = lap3d(12, 11, 10, 1.0, 1.01, 1.02)
+
+    def run():
+        np.random.seed(1)
+        opt = Options()
+        opt.max_iter = 30
+        before = dict(fake.calls)
+        lmd, x, status = partial_hevp(A, T=True, which=5, tol=1e-13, verb=-1, opt=opt)
+        its = partial_hevp.last['iterations']
+        return its, fake.calls.get('sync', 0) - before.get('sync', 0), evp_values()
+
+    def evp_values():
+        return None
+    its, syncs, _ = run()
+    assert its == 30                                   # the tolerance is out of reach: no locking, steady state
+    assert syncs <= 5 * its + 8                        # 5 per iteration + the set-up (start block, initial Rayleigh-Ritz)
+    assert fake.calls.get('gram_multi', 0) >= 3 * its  # the stacked Grams ran
+    # the same run with one blocking call per reduction, as the reference issues them
+    monkeypatch.delattr(Vectors, 'reduction_batch')
+    its2, syncs2, _ = run()
+    assert its2 == its and syncs2 >= 11 * its
+
+
+def test_batched_and_unbatched_drivers_agree(monkeypatch):
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip import Vectors
+    from oracle.sparse import lap3d, lap3d_eigenvalues
+    A = lap3d(12, 11, 10, 1.0, 1.01, 1.02)
+    exact = lap3d_eigenvalues(12, 11, 10, 1.0, 1.01, 1.02, 6)
+    out = []
+    for batched in (True, False):
+        if not batched:
+            monkeypatch.delattr(Vectors, 'reduction_batch')
+        np.random.seed(1)
+        from raleigh_amd.core.solver import Options
+        opt = Options()
+        opt.max_iter = 500
+        lmd, x, status = partial_hevp(A, T=True, which=6, tol=1e-8, verb=-1, opt=opt)
+        assert status == 0 and np.allclose(lmd[:6], exact, rtol=1e-10)
+        out.append((lmd[:6], partial_hevp.last['iterations']))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-12)
+    assert abs(out[0][1] - out[1][1]) <= max(2, out[1][1] // 20)
