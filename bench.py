@@ -4,19 +4,23 @@ raleigh/core/solver.py:854-861,968-974,1321-1339,1360,1376-1381,1444-1447) on a
 synthetic n x m block, n = 215^3 = 9 938 375 (the "n = 10^7" roofline point of
 BASELINE.json), m = 32, fp64, A = 7-point 3-D Laplacian.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the rows
 are sharded over the ranks, every Gram / dots carries one all-reduce, the SpMM
-one halo exchange.  Weak scaling: every GPU holds a 215^3-row shard (the grid
-grows along z: 215 x 215 x 215 N), so per-GPU work is fixed and `value` is the
-aggregate over the N GPUs.
+one halo exchange.  `--scaling weak` (default): every GPU holds a 215^3-row shard
+(the grid grows along z: 215 x 215 x 215 N), per-GPU work is fixed and `value` is the
+aggregate over the N GPUs.  `--scaling strong`: the 215^3 rows are split over the N
+ranks (the north-star's ">= 6x at 8 GPUs at n = 10M" question); at N = 1 the two are
+the same workload.  With N > 1 the run also reports the other mode under "also".
 
 Prints ONE JSON line (rank 0).  `value` = algorithmic GB/s of the whole job:
 bytes of SURVEY 8(d) (9 Gram calls = 16 blocks, 4 self-dots = 4 blocks, one
 SpMM = nnz*12 + (n+1)*4 + 2 blocks) divided by the max-over-ranks step time,
 operands resident in HBM, every dot/dots returning its result to the host as the
-solver requires.
+solver requires.  The step time is the wall-clock mean over the K steps between two
+barriers (the driver's contract); the median of per-step HIP-event times is reported
+beside it.
 """
 
 import argparse
@@ -34,25 +38,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 
 
-def lap3d_rows(nx, ny, nz, ax, ay, az, r0, r1):
-    """Rows [r0, r1) of the 7-point Laplacian of raleigh/examples/laplace.py:23-27 as a full
-    (both triangles) CSR block with GLOBAL column indices, built without the global matrix."""
-    import scipy.sparse as sp
-    n = nx * ny * nz
-    r = np.arange(r0, r1, dtype=np.int64)
-    ix, iy, iz = r % nx, (r // nx) % ny, r // (nx * ny)
-    cx, cy, cz = ((nx + 1.0) / ax) ** 2, ((ny + 1.0) / ay) ** 2, ((nz + 1.0) / az) ** 2
-    rows, cols, vals = [r], [r], [np.full(r.shape, 2 * (cx + cy + cz))]
-    for cond, shift, c in ((ix > 0, -1, cx), (ix < nx - 1, 1, cx), (iy > 0, -nx, cy), (iy < ny - 1, nx, cy),
-                           (iz > 0, -nx * ny, cz), (iz < nz - 1, nx * ny, cz)):
-        rows.append(r[cond]); cols.append(r[cond] + shift); vals.append(np.full(int(cond.sum()), -c))
-    rows = np.concatenate(rows) - r0
-    blk = sp.csr_matrix((np.concatenate(vals), (rows, np.concatenate(cols))), shape=(r1 - r0, n))
-    blk.sort_indices()
-    return blk
-
-
-
 class InnerIteration:
     """The Gram / dots / SpMM sequence of one steady-state iteration (standard problem,
     identity preconditioner, no deflation) on blocks X, AX, Y, AY, Z, AZ, W."""
@@ -61,6 +46,7 @@ class InnerIteration:
         self.b, self.op = blocks, op
 
     def headline(self):
+        """One blocking call per reduction, in the reference driver's order (13 host round trips)."""
         X, AX, Y, AY, Z, AZ, W = self.b
         out = []
         out.append(AX.dot(X))       # XAX   solver.py:857
@@ -77,6 +63,30 @@ class InnerIteration:
         self.op.apply(Y, AY)        # AY = A Y, solver.py:1444
         out.append(AY.dot(X))       # XAY   solver.py:1446
         out.append(AY.dot(Y))       # YAY   solver.py:1447
+        return out
+
+    def fused(self):
+        """The same quantities as this repository's driver requests them (raleigh_amd/core/solver.py):
+        stacked Grams that read every block once and five batches = five host round trips."""
+        X, AX, Y, AY, Z, AZ, W = self.b
+        out = []
+        rb = X.reduction_batch()
+        rb.gram([X], [AX, X])       # XAX, XBX
+        rb.dots(W, W)               # residual norms
+        out.append(rb.run())
+        rb = Y.reduction_batch()
+        rb.gram([Y], [AZ, Z])       # ZAY, ZBY
+        rb.dots(Y, Y)
+        rb.dots(Z, Z)
+        out.append(rb.run())
+        out.append(Y.dot(X))        # Q
+        rb = Y.reduction_batch()
+        rb.gram([Y], [X, Y])        # XBY, YBY (+ the norms of Y on its diagonal)
+        out.append(rb.run())
+        self.op.apply(Y, AY)
+        rb = AY.reduction_batch()
+        rb.gram([AY], [X, Y])       # XAY, YAY
+        out.append(rb.run())
         return out
 
     def all_ops(self, q):
@@ -106,37 +116,82 @@ class InnerIteration:
         spmm = nnz * (es + 4) + (n + 1) * 4 + 2 * B
         return gram + dots + spmm, {'gram': gram, 'dots': dots, 'spmm': spmm}
 
+    @staticmethod
+    def fused_bytes(n, m, es, nnz):
+        B = n * m * es                    # stacked Grams: 3 + 3 + 2 + 2 + 3 blocks, dots 3 blocks
+        return 13 * B + 3 * B + nnz * (es + 4) + (n + 1) * 4 + 2 * B
 
-def cpu_baseline(m, reps_target_s=12.0):
-    """The CPU oracle (oracle/, NumPy + the node's BLAS, SciPy SpMM) timed on a bounded sample
-    of the same workload: lap3d 100^3 (n = 10^6), m = 32, fp64."""
-    from oracle import Vectors as OV, SparseSymmetricMatrix as OS
-    from oracle.sparse import lap3d
-    N = 100
-    A = lap3d(N, N, N, 1.0, 1.01, 1.02)
-    n = A.shape[0]
-    rng = np.random.default_rng(1)
-    blocks = [OV(2 * rng.random((m, n)) - 1) for _ in range(7)]
-    it = InnerIteration(blocks, OS(A))
-    it.headline()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        it.headline()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > reps_target_s or reps >= 20:
-            break
-    nbytes, _ = InnerIteration.headline_bytes(n, m, 8, A.nnz)
+
+def host_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+        return int(max([p.get('num_threads', 1) for p in threadpool_info()] or [1]))
     except Exception:
-        threads = os.cpu_count() or 1
-    return {'value': round(nbytes * reps / el / 1e9, 3), 'unit': 'GB/s', 'cores': int(threads),
-            'kind': 'port',
-            'sample': 'oracle (NumPy/BLAS + SciPy CSR) inner iteration, lap3d 100^3 (n=1e6), m=%d fp64, %d reps in %.1f s'
-                      % (m, reps, el)}
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(side, m, budget_s=20.0):
+    """The CPU oracle (oracle/: NumPy + the node's BLAS, SciPy CSR SpMM) on the SAME workload as the
+    GPU headline -- lap3d side^3, m vectors, fp64, the same 14 calls -- timed on the host cores for a
+    bounded number of repetitions (at 215^3 one repetition moves 57 GB: 2-3 repetitions)."""
+    from oracle import Vectors as OV, SparseSymmetricMatrix as OS
+    from raleigh_amd.synthetic import lap3d_rows
+    n = side ** 3
+    A = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, 0, n)
+    rng = np.random.default_rng(1)
+    first = 2 * rng.random((m, n)) - 1
+    blocks = [OV(first)]
+    for i in range(1, 7):
+        blocks.append(OV(np.roll(first, i, axis=0) * (1.0 + 0.37 * i)))
+    it = InnerIteration(blocks, OS(A))
+    t0 = time.perf_counter()
+    it.headline()                                        # (first repetition: also warms the BLAS threads up)
+    first_s = time.perf_counter() - t0
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or (time.perf_counter() - t0 + first_s * 1.2 < budget_s and reps < 5):
+        it.headline()
+        reps += 1
+    el = time.perf_counter() - t0
+    nbytes, _ = InnerIteration.headline_bytes(n, m, 8, A.nnz)
+    return {'value': round(nbytes * reps / el / 1e9, 3), 'unit': 'GB/s', 'cores': host_threads(), 'kind': 'port',
+            'sample': 'oracle (NumPy/BLAS + SciPy CSR) on the same input as the GPU headline: lap3d %d^3 (n=%d), m=%d '
+                      'fp64, %d repetition(s) of the 14-call inner iteration in %.1f s' % (side, n, m, reps, el)}
+
+
+def lap_operator(side, dtype, comm, off, nz=None):
+    """(operator with apply / cheb_step / size / data_type, vectors factory) for lap3d side x side x nz."""
+    from raleigh_amd.synthetic import lap3d_rows
+    nz = side if nz is None else nz
+    n = side * side * nz
+    if comm is None:
+        from raleigh_amd.algebra.hip import CsrOperator
+
+        class Op:
+            def __init__(self):
+                self.csr = CsrOperator(lap3d_rows(side, side, nz, 1.0, 1.01, 1.02 * nz / side, 0, n).astype(dtype))
+
+            def size(self):
+                return n
+
+            def data_type(self):
+                return dtype
+
+            def apply(self, x, y):
+                self.csr.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
+
+            def cheb_step(self, y, p, b, cy, cp, cb):
+                self.csr.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
+
+            def supports_bf16(self):
+                return dtype == np.float32 and self.csr.layout()[0] == 'well'
+
+            def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
+                self.csr.cheb_step_bf16(m, y, p, b, cy, cp, cb)
+        return Op()
+    from raleigh_amd.algebra.hip.dist import ShardedSparseMatrix
+    r0, r1 = int(off[comm.rank]), int(off[comm.rank + 1])
+    rows = lap3d_rows(side, side, nz, 1.0, 1.01, 1.02 * nz / side, r0, r1).astype(dtype)
+    return ShardedSparseMatrix.from_local_rows(rows, r0, n, comm, off)
 
 
 def solve_ten(side, comm):
@@ -146,62 +201,195 @@ def solve_ten(side, comm):
     ranks; checked against the analytic spectrum."""
     from raleigh_amd.interfaces import partial_hevp
     from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner
     from oracle.sparse import lap3d_eigenvalues
     n = side ** 3
     np.random.seed(1)
     opt = Options()
     opt.max_iter = 5000
-    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner
-    if comm is None:
-        from raleigh_amd.algebra.hip import CsrOperator
-
-        class Op:
-            def __init__(self, dtype):
-                rows = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, 0, n)
-                self.csr = CsrOperator(rows.astype(dtype))
-                self.dtype = dtype
-
-            def size(self):
-                return n
-
-            def data_type(self):
-                return self.dtype
-
-            def apply(self, x, y):
-                self.csr.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
-
-            def cheb_step(self, y, p, b, cy, cp, cb):
-                self.csr.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
-
-            def supports_bf16(self):
-                return self.dtype == np.float32 and self.csr.layout()[0] == 'well'
-
-            def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
-                self.csr.cheb_step_bf16(m, y, p, b, cy, cp, cb)
-        op, op32, vectors = Op(np.float64), Op(np.float32), None
-    else:
-        from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix, partition
+    vectors, off = None, None
+    if comm is not None:
+        from raleigh_amd.algebra.hip.dist import ShardedVectors, partition
         off = partition(n, comm.size)
-        r0, r1 = int(off[comm.rank]), int(off[comm.rank + 1])
-        rows = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, r0, r1)
-        op = ShardedSparseMatrix.from_local_rows(rows, r0, n, comm, off)
-        op32 = ShardedSparseMatrix.from_local_rows(rows.astype(np.float32), r0, n, comm, off)
         vectors = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=off)
+    op, op32 = lap_operator(side, np.float64, comm, off), lap_operator(side, np.float32, comm, off)
     # device-resident Chebyshev polynomial preconditioner (degree 32 on [hi/7000, hi], hi = the
     # Gershgorin bound 4 (cx + cy + cz) of the stencil), evaluated in float32: every block stays in HBM
-    hi = 4.0 * sum(((side + 1.0) / a) ** 2 for a in (1.0, 1.01, 1.02))
     # (work blocks in bfloat16, float32 arithmetic; row shards exchange 2-byte halo rows)
+    hi = 4.0 * sum(((side + 1.0) / a) ** 2 for a in (1.0, 1.01, 1.02))
     T = ChebyshevPreconditioner(None, hi, ratio=7000.0, degree=32, low_precision_op=op32, storage='bf16')
     t0 = time.perf_counter()
-    lmd, x, status = partial_hevp(None, T=T, which=10, tol=1e-6, verb=-1, opt=opt, vectors=vectors,
-                                  operator=op)
+    lmd, x, status = partial_hevp(None, T=T, which=10, tol=1e-6, verb=-1, opt=opt, vectors=vectors, operator=op)
     seconds = time.perf_counter() - t0
     ana = lap3d_eigenvalues(side, side, side, 1.0, 1.01, 1.02, 10)
     err = float(np.max(np.abs(lmd[:10] - ana) / ana)) if status == 0 and len(lmd) >= 10 else None
     return {'problem': 'lap3d %d^3 (n=%d), 10 smallest eigenpairs, eigenvector tol 1e-6, device Chebyshev '
-                       'preconditioner (degree 32, float32 arithmetic, bfloat16 work blocks), rows sharded over the ranks' % (side, n),
+                       'preconditioner (degree 32, float32 arithmetic, bfloat16 work blocks; not one of the '
+                       'reference\'s preconditioners: see solve_ilu for its ILU), rows sharded over the ranks' % (side, n),
             'seconds': round(seconds, 3), 'status': int(status), 'iterations': int(partial_hevp.last['iterations']),
             'max_rel_eigenvalue_error': err}
+
+
+def solve_ilu_pair(side):
+    """The reference's own configuration -- partial_hevp(A, T=IncompleteLU(A), which=10), ILUT(1e-6, fill 1)
+    as sparse_mkl.py:122-140 -- on lap3d side^3: on the GPU (host ILUT once, level-scheduled triangular
+    solves on the device) and, beside it, the same driver on the CPU oracle backend with the same factors
+    (SciPy triangular solves), both timed from the factorised preconditioner to ten eigenpairs."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip.precond import IncompleteLU, ilut
+    from raleigh_amd.core.solver import Options, Problem, Solver, DefaultConvergenceCriteria
+    from raleigh_amd.synthetic import lap3d_rows
+    from oracle import Vectors as OV, SparseSymmetricMatrix as OS
+    from oracle.sparse import lap3d_eigenvalues
+    n = side ** 3
+    A = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, 0, n)
+    ana = lap3d_eigenvalues(side, side, side, 1.0, 1.01, 1.02, 10)
+    out = {'problem': 'lap3d %d^3 (n=%d), 10 smallest eigenpairs, eigenvector tol 1e-6, ILUT(1e-6, fill 1) '
+                      'preconditioner as the reference\'s IncompleteLU' % (side, n)}
+    t0 = time.perf_counter()
+    T = IncompleteLU(A)
+    T.factorize()
+    out['ilut_host_seconds'] = round(time.perf_counter() - t0, 3)
+    out['levels'] = list(T.levels)
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 2000
+    t0 = time.perf_counter()
+    lmd, x, status = partial_hevp(A, T=T, which=10, tol=1e-6, verb=-1, opt=opt)
+    out['gpu'] = {'seconds': round(time.perf_counter() - t0, 3), 'status': int(status),
+                  'iterations': int(partial_hevp.last['iterations']),
+                  'max_rel_eigenvalue_error': float(np.max(np.abs(lmd[:10] - ana) / ana)) if status == 0 else None}
+    # CPU: the same driver on the oracle's Vectors, the same ILUT factors
+    lo, up = ilut(A, 1e-6, min(n - 1, A.nnz // n))
+    lo1 = sp.csr_matrix(lo + sp.identity(n))
+
+    class HostILU:
+        def apply(self, x, y):
+            w = sla.spsolve_triangular(lo1, x.data().T, lower=True)
+            y.fill(np.ascontiguousarray(sla.spsolve_triangular(up, w, lower=False).T))
+    np.random.seed(1)
+    ev = OV(n, 0, data_type=np.float64)
+    solver = Solver(Problem(ev, OS(A)))
+    solver.set_preconditioner(HostILU())
+    opt = Options()
+    opt.max_iter = 2000
+    opt.convergence_criteria = DefaultConvergenceCriteria()
+    opt.convergence_criteria.set_error_tolerance('k eigenvector error', 1e-6)
+    t0 = time.perf_counter()
+    status = solver.solve(ev, opt, which=(10, 0))
+    lc = np.sort(solver.eigenvalues)
+    out['cpu'] = {'seconds': round(time.perf_counter() - t0, 3), 'status': int(status), 'iterations': int(solver.iteration),
+                  'cores': host_threads(), 'kind': 'port',
+                  'max_rel_eigenvalue_error': float(np.max(np.abs(lc[:10] - ana) / ana)) if len(lc) >= 10 else None}
+    return out
+
+
+def timed_calls(L, fn, reps):
+    """Median HIP-event time (ms) of `reps` back-to-back calls of fn on the library stream."""
+    from raleigh_amd import _lib
+    ms = ctypes.c_float()
+    fn()
+    _lib.check(L.rlh_sync())
+    ts = []
+    for _ in range(reps):
+        _lib.check(L.rlh_timer_start())
+        fn()
+        _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
+        ts.append(ms.value)
+    return float(np.median(ts))
+
+
+def config_legs(L):
+    """Per-configuration figures of BASELINE.json's other configs on one GPU (reported beside the
+    headline, not part of `value`): config 3 (FE-like shipsec5 surrogate: SpMM roofline, ILU solve),
+    config 5 (complex128, m = 64: Gram / SpMM / update at n = 126^3), config 2 (pca 20000^2, npc = 200)."""
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import fe_surrogate, hermitian_lap3d_rows
+    out = {}
+    # ---- config 3
+    A = fe_surrogate()
+    n, m = A.shape[0], 16
+    op = CsrOperator(A)
+    X, Y = Vectors(n, m), Vectors(n, m)
+    X.fill_random()
+    t = timed_calls(L, lambda: op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld()), 30)
+    nbytes = A.nnz * 12 + (n + 1) * 4 + 2 * n * m * 8
+    c3 = {'workload': 'FE-like shipsec5 surrogate n=%d nnz=%d (%.1f per row), fp64, m=%d' % (n, A.nnz, A.nnz / n, m),
+          'spmm_ms': round(t, 4), 'spmm_gbs': round(nbytes / t / 1e6, 1), 'spmm_frac_of_hbm_peak': round(nbytes / t / 1e6 / HBM_PEAK_GBS, 4),
+          'layout': op.layout()[0]}
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip.precond import IncompleteLU
+    np.random.seed(1)
+    T = IncompleteLU(A)
+    t0 = time.perf_counter()
+    T.factorize()
+    c3['ilut_host_seconds'] = round(time.perf_counter() - t0, 2)
+    B_, Z_ = Vectors(n, m), Vectors(n, m)
+    B_.fill_random()
+    ta = timed_calls(L, lambda: T.apply(B_, Z_), 5)
+    c3['ilu_apply_ms'] = round(ta, 3)
+    c3['ilu_apply_gbs'] = round(T.chain().algorithmic_bytes(m) / ta / 1e6, 1)
+    c3['ilu_levels'] = list(T.levels)
+    t0 = time.perf_counter()
+    lmd, x, status = partial_hevp(A, T=T, which=10, tol=1e-6, verb=-1)
+    c3['solve'] = {'seconds': round(time.perf_counter() - t0, 3), 'status': int(status),
+                   'iterations': int(partial_hevp.last['iterations']), 'smallest': [float(v) for v in lmd[:3]]}
+    out['config3'] = c3
+    del op, X, Y, T, B_, Z_
+    # ---- config 5 (one GPU: n = 126^3, complex128, m = 64)
+    N, m = 126, 64
+    n = N ** 3
+    H = hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n)
+    op = CsrOperator(H)
+    X, Y, W = (Vectors(n, m, data_type=np.complex128) for _ in range(3))
+    X.fill_random()
+    X.copy(Y)
+    code = _lib.dtype_code(np.complex128)
+    res = ctypes.c_void_p()
+    _lib.check(L.rlh_malloc(ctypes.byref(res), m * m * 16))
+    B = n * m * 16
+    q = (np.random.default_rng(2).standard_normal((m, m)) / m).astype(np.complex128)
+    a1 = np.array([1.0, 0.0])
+    legs = {
+        'gram': (2 * B, 8.0 * n * m * m, lambda: _lib.check(L.rlh_gram(code, n, m, X.data_ptr(), X.ld(), m, Y.data_ptr(), Y.ld(), res, None))),
+        'self_gram': (B, 4.0 * n * m * m, lambda: _lib.check(L.rlh_gram(code, n, m, X.data_ptr(), X.ld(), m, X.data_ptr(), X.ld(), res, None))),
+        'multiply': (2 * B, 8.0 * n * m * m, lambda: _lib.check(L.rlh_block_update(code, n, m, X.data_ptr(), X.ld(), m, W.data_ptr(), W.ld(),
+                                                                                   _lib.host_ptr(q), m, 1, _lib.host_ptr(a1), 0))),
+        'spmm': (H.nnz * 20 + (n + 1) * 4 + 2 * B, 8.0 * H.nnz * m, lambda: op.apply_ptr(m, X.data_ptr(), X.ld(), W.data_ptr(), W.ld())),
+    }
+    c5 = {'workload': 'Hermitian lap3d + i skew, n=126^3=%d, complex128, m=%d (blocks of %.2f GB)' % (n, m, B / 1e9)}
+    for name, (nb, flops, fn) in legs.items():
+        t = timed_calls(L, fn, 10)
+        c5[name] = {'ms': round(t, 3), 'gbs': round(nb / t / 1e6, 1), 'frac_of_hbm_peak': round(nb / t / 1e6 / HBM_PEAK_GBS, 4),
+                    'tflops': round(flops / t / 1e9, 1), 'frac_of_fp64_peak_78.6': round(flops / t / 1e9 / 78.6, 4)}
+    out['config5'] = c5
+    _lib.check(L.rlh_free(res))
+    del op, X, Y, W
+    # ---- config 2
+    from raleigh_amd.interfaces import pca
+    M = Nn = 20000
+    r, npc = 400, 200
+    rng = np.random.default_rng(1)
+    U = rng.standard_normal((M, r)).astype(np.float32)
+    U[:, 0] = 1.0
+    V = rng.standard_normal((Nn, r)).astype(np.float32)
+    U, _ = np.linalg.qr(U)
+    V, _ = np.linalg.qr(V)
+    s = np.sort(rng.random(min(M, Nn)).astype(np.float32)) ** (-0.75)
+    s = (s / s[0])[:r]
+    Am = np.ascontiguousarray((U * s) @ V.T, dtype=np.float32)
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    mean, trans, comps = pca(Am, npc=npc)
+    el = time.perf_counter() - t0
+    sv = np.linalg.norm(trans, axis=0)
+    out['config2'] = {'workload': 'pca of a dense 20000 x 20000 fp32 matrix, 200 components', 'seconds': round(el, 3),
+                      'iterations': int(pca.last['iterations']), 'operator_seconds': round(float(pca.last['operator_time']), 3),
+                      'max_sigma_error_over_sigma_max': float(np.max(np.abs(sv - s[1:npc + 1])) / s[1])}
+    return out
 
 
 def main():
@@ -211,11 +399,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--side', type=int, default=215, help='lap3d side (n = side^3)')
     ap.add_argument('--m', type=int, default=32)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the config 2 / 3 / 5 legs (N = 1 only)')
     ap.add_argument('--force-dist', action='store_true',
-                    help='use the sharded (torch.distributed / RCCL) code path even with one rank')
+                    help='use the sharded (torch.distributed / RCCL) code path even with one rank, all-reduce and '
+                         'halo exchange included (a rank then exchanges with itself)')
     ap.add_argument('--solve-side', type=int, default=215,
                     help='lap3d side of the end-to-end "seconds to 10 eigenpairs" run (0: skip)')
+    ap.add_argument('--ilu-side', type=int, default=64,
+                    help='lap3d side of the GPU-vs-CPU solve with the reference\'s ILU preconditioner (0: skip)')
     args = ap.parse_args()
 
     # Everything any library prints (RCCL prints a version banner on stdout) goes to stderr;
@@ -232,7 +425,7 @@ def main():
                          % (args.gpus, args.gpus))
 
     from raleigh_amd import _lib
-    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.algebra.hip import Vectors
     comm = None
     if world > 1 or args.force_dist:
         import torch
@@ -241,48 +434,10 @@ def main():
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, ShardedSparseMatrix, partition
-        comm = Comm()
+        from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, partition
+        comm = Comm(force_collectives=True if args.force_dist else None)
     L = _lib.lib(local_rank)
-
     side, m, es = args.side, args.m, 8
-    nzg = side * world                           # weak scaling: the grid grows along z with the GPUs
-    n = side * side * nzg
-    nnz = 7 * n - 2 * (side * nzg * 2 + side * side)      # 7-point stencil minus the six faces
-    if comm is None:
-        r0, r1 = 0, n
-    else:
-        off = partition(n, world)
-        r0, r1 = int(off[rank]), int(off[rank + 1])
-    nloc = r1 - r0
-
-    # ---- synthetic inputs, resident in HBM before the timed region
-    rng = np.random.default_rng(1 + rank)
-    if comm is None:
-        mk = lambda: Vectors(nloc, m, data_type=np.float64)
-    else:
-        mk = lambda: ShardedVectors(n, m, np.float64, comm=comm, offsets=off)
-    blocks = [mk() for _ in range(7)]
-    for j in range(m):                            # U(-1, 1), one vector at a time (bounded host memory)
-        blocks[0].select(1, j)
-        Vectors.fill(blocks[0], 2 * rng.random((1, nloc)) - 1)
-    blocks[0].select(m)
-    for i, b in enumerate(blocks[1:], 1):         # distinct random-looking blocks from device-side ops
-        blocks[0].copy(b, np.roll(np.arange(m), i))
-        b.add(blocks[0], 0.37 * i)
-    rows = lap3d_rows(side, side, nzg, 1.0, 1.01, 1.02 * world, r0, r1)
-    assert world > 1 or rows.nnz == nnz
-    if comm is None:
-        csr = CsrOperator(rows)
-
-        class Op:
-            def apply(self, x, y):
-                csr.apply_ptr(x.nvec(), x.data_ptr(), x.ld(), y.data_ptr(), y.ld())
-        op = Op()
-    else:
-        op = ShardedSparseMatrix.from_local_rows(rows, r0, n, comm, off)
-    del rows
-    it = InnerIteration(blocks, op)
 
     def sync_all():
         _lib.check(L.rlh_sync())
@@ -292,50 +447,110 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        it.headline()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        it.headline()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if comm is not None:
+    def max_over_ranks(x):
+        if comm is None:
+            return x
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([x], dtype=torch.float64, device='cuda')
         comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    nbytes, parts = InnerIteration.headline_bytes(n, m, es, nnz)
-    value = nbytes / (ms_per_step * 1e-3) / 1e9
+        return float(t.item())
 
-    # ---- the all-ops figure beside the headline (reported, not the metric): a few steps of the full mix
-    q = np.eye(m) + 1e-3 * np.random.default_rng(7).standard_normal((m, m))
-    it.all_ops(q)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        it.all_ops(q)
-    sync_all()
-    all_ms = (time.perf_counter() - t0) / 5 * 1e3
-    all_bytes = InnerIteration.all_ops_bytes(n, m, es, nnz)
+    def run_mode(mode, steps, warmup, extras):
+        """Times `steps` headline iterations on lap3d side x side x nzg (weak: nzg = side * world)."""
+        nzg = side * world if mode == 'weak' else side
+        n = side * side * nzg
+        nnz = 7 * n - 2 * (side * nzg * 2 + side * side)      # 7-point stencil minus the six faces
+        off = None
+        if comm is None:
+            nloc = n
+            mk = lambda: Vectors(nloc, m, data_type=np.float64)
+        else:
+            off = partition(n, world)
+            nloc = int(off[rank + 1] - off[rank])
+            mk = lambda: ShardedVectors(n, m, np.float64, comm=comm, offsets=off)
+        # ---- synthetic inputs, resident in HBM before the timed region
+        rng = np.random.default_rng(1 + rank)
+        blocks = [mk() for _ in range(7)]
+        for j in range(m):                            # U(-1, 1), one vector at a time (bounded host memory)
+            blocks[0].select(1, j)
+            Vectors.fill(blocks[0], 2 * rng.random((1, nloc)) - 1)
+        blocks[0].select(m)
+        for i, b in enumerate(blocks[1:], 1):         # distinct random-looking blocks from device-side ops
+            blocks[0].copy(b, np.roll(np.arange(m), i))
+            b.add(blocks[0], 0.37 * i)
+        op = lap_operator(side, np.float64, comm, off, nz=nzg)
+        it = InnerIteration(blocks, op)
+        for _ in range(warmup):
+            it.headline()
+        sync_all()
+        ms = ctypes.c_float()
+        per_step = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _lib.check(L.rlh_timer_start())
+            it.headline()
+            _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
+            per_step.append(ms.value)
+        sync_all()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        ms_per_step = elapsed / steps * 1e3
+        nbytes, parts = InnerIteration.headline_bytes(n, m, es, nnz)
+        res = {'mode': mode, 'n': n, 'nnz': nnz, 'nzg': nzg, 'nloc': nloc, 'ms_per_step': ms_per_step,
+               'median_ms': max_over_ranks(float(np.median(per_step))), 'nbytes': nbytes, 'parts': parts,
+               'value': nbytes / (ms_per_step * 1e-3) / 1e9}
+        if extras:
+            # the same quantities as the repository's own driver asks for them: stacked Grams, 5 round trips
+            it.fused()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                it.fused()
+            sync_all()
+            f_ms = max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+            fb = InnerIteration.fused_bytes(n, m, es, nnz)
+            res['fused'] = {'ms_per_step': round(f_ms, 4), 'host_round_trips_per_step': 5,
+                            'algorithmic_bytes_per_step': fb, 'gbs': round(fb / (f_ms * 1e-3) / 1e9, 1),
+                            'what': 'the reductions of one iteration as raleigh_amd/core/solver.py issues them: stacked '
+                                    'Grams [AX|X]^H X, [AZ|Z]^H Y, [X|Y]^H Y, [X|Y]^H AY (every block read once) in 5 batches'}
+            # the all-ops figure beside the headline (reported, not the metric): a few steps of the full mix
+            q = np.eye(m) + 1e-3 * np.random.default_rng(7).standard_normal((m, m))
+            it.all_ops(q)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                it.all_ops(q)
+            sync_all()
+            all_ms = max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
+            all_bytes = InnerIteration.all_ops_bytes(n, m, es, nnz)
+            res['all_ops'] = {'ms_per_step': round(all_ms, 3), 'algorithmic_bytes_per_step': all_bytes,
+                              'gbs': round(all_bytes / (all_ms * 1e-3) / 1e9, 1),
+                              'what': 'headline + 4 multiply + 7 add(q) + 6 copy + 1 scale (the reference driver\'s per-iteration mix)'}
+            # roofline of the dominant kernel (two-operand Gram), HIP events on the kernels' stream
+            X, AX = blocks[0], blocks[1]
+            rbuf = ctypes.c_void_p()
+            _lib.check(L.rlh_malloc(ctypes.byref(rbuf), m * m * es))
+            code = _lib.dtype_code(np.float64)
+            gram = lambda: L.rlh_gram(code, nloc, m, X.data_ptr(), X.ld(), m, AX.data_ptr(), AX.ld(), rbuf, None)
+            reps = 20
+            _lib.check(gram())
+            _lib.check(L.rlh_timer_start())
+            for _ in range(reps):
+                _lib.check(gram())
+            _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
+            _lib.check(L.rlh_free(rbuf))
+            res['gram_ms'] = ms.value / reps
+            res['gram_bytes'] = 2 * nloc * m * es
+        return res
 
-    # ---- roofline of the dominant kernel (two-operand Gram), HIP events on the kernels' stream
-    X, AX = blocks[0], blocks[1]
-    ms = ctypes.c_float()
-    res = ctypes.c_void_p()
-    _lib.check(L.rlh_malloc(ctypes.byref(res), m * m * es))
-    code = _lib.dtype_code(np.float64)
-    reps = 20
-    gram = lambda: L.rlh_gram(code, nloc, m, X.data_ptr(), X.ld(), m, AX.data_ptr(), AX.ld(), res, None)
-    _lib.check(gram())
-    _lib.check(L.rlh_timer_start())
-    for _ in range(reps):
-        _lib.check(gram())
-    _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
-    gram_ms = ms.value / reps
-    gram_bytes = 2 * nloc * m * es
-    achieved = gram_bytes / (gram_ms * 1e-3) / 1e9
+    main_res = run_mode(args.scaling, args.steps, args.warmup, True)
+    also = None
+    if world > 1:
+        other = 'strong' if args.scaling == 'weak' else 'weak'
+        r2 = run_mode(other, max(3, args.steps // 2), 2, False)
+        also = {'scaling': other, 'value': round(r2['value'], 1), 'unit': 'GB/s', 'ms_per_step': round(r2['ms_per_step'], 4),
+                'n': r2['n'], 'rows_per_gpu': r2['nloc']}
+
+    achieved = main_res['gram_bytes'] / (main_res['gram_ms'] * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'gram_traffic.json')
     if os.path.exists(tpath) and world == 1:
@@ -346,34 +561,57 @@ def main():
     roofline = {'bound': 'hbm', 'kernel': 'gram_kernel<fp64, 2x2 tiles> (X.dot(Y), m=k=%d)' % m,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'algorithmic_bytes_per_launch': gram_bytes, 'avg_launch_ms': round(gram_ms, 4),
-                'inner_iteration_frac': round(value / world / HBM_PEAK_GBS, 4)}
-
+                'algorithmic_bytes_per_launch': main_res['gram_bytes'], 'avg_launch_ms': round(main_res['gram_ms'], 4),
+                'inner_iteration_frac': round(main_res['value'] / world / HBM_PEAK_GBS, 4)}
+    n, nnz, nzg = main_res['n'], main_res['nnz'], main_res['nzg']
     out = {'metric': 'inner-iter GB/s vs HBM roofline (Gram+dots+SpMM of one block-JCG iteration)',
-           'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
-           'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'value': round(main_res['value'], 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(main_res['ms_per_step'], 4), 'higher_is_better': True,
+           'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': 'block-JCG inner iteration: 9 Gram + 4 dots + 1 SpMM, n=%dx%dx%d=%d rows '
-                                  '(%d^3 per GPU), m=%d, 7-pt Laplacian nnz=%d, rows sharded over %d GPU(s)'
-                                  % (side, side, nzg, n, side, m, nnz, world),
-                      'n': n, 'm': m, 'nnz': nnz, 'algorithmic_bytes_per_step': nbytes,
-                      'bytes_breakdown': parts},
-           'roofline': roofline,
-           'all_ops': {'ms_per_step': round(all_ms, 3), 'algorithmic_bytes_per_step': all_bytes,
-                       'gbs': round(all_bytes / (all_ms * 1e-3) / 1e9, 1),
-                       'what': 'headline + 4 multiply + 7 add(q) + 6 copy + 1 scale (the reference driver\'s per-iteration mix)'}}
-    if args.solve_side > 0:
+                                  '(%d per GPU), m=%d, 7-pt Laplacian nnz=%d, rows sharded over %d GPU(s), %s scaling'
+                                  % (side, side, nzg, n, main_res['nloc'], m, nnz, world, args.scaling),
+                      'n': n, 'm': m, 'nnz': nnz, 'algorithmic_bytes_per_step': main_res['nbytes'],
+                      'bytes_breakdown': main_res['parts']},
+           'ms_per_step_median_hip_events': round(main_res['median_ms'], 4),
+           'roofline': roofline, 'fused': main_res['fused'], 'all_ops': main_res['all_ops']}
+    if also is not None:
+        out['also'] = also
+    if comm is not None:
+        out['collectives'] = {'backend': 'nccl (RCCL)', 'forced_at_one_rank': bool(args.force_dist)}
+
+    def guarded(key, fn):
+        """A failure on ANY rank is agreed on by all of them (the others would otherwise wait in the next
+        collective); the line reports it and the process exits non-zero after printing."""
+        err = None
         try:
-            out['solve'] = solve_ten(args.solve_side, comm)
-        except Exception as e:      # the headline above is already measured: report, do not lose the line
-            out['solve'] = {'error': '%s: %s' % (type(e).__name__, e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(m)
+            val = fn()
+        except Exception as e:
+            val, err = None, '%s: %s' % (type(e).__name__, e)
+        failed = max_over_ranks(1.0 if err else 0.0)
+        if failed:
+            out[key] = {'error': err or 'failed on another rank'}
+            return False
+        out[key] = val
+        return True
+
+    ok = True
+    if args.solve_side > 0:
+        ok = guarded('solve', lambda: solve_ten(args.solve_side, comm)) and ok
+    if world == 1 and comm is None:
+        if args.ilu_side > 0:
+            ok = guarded('solve_ilu', lambda: solve_ilu_pair(args.ilu_side)) and ok
+        if not args.no_configs:
+            ok = guarded('configs', lambda: config_legs(L)) and ok
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(side, m)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if comm is not None:
         comm.dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

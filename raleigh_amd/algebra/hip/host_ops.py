@@ -48,14 +48,21 @@ class IncompleteLU:
 
 
 class SparseSymmetricSolver:
-    """Host LU of A - sigma B (counterpart of sparse_mkl.py:51-119 on SuperLU).
+    """LU of A - sigma B (counterpart of sparse_mkl.py:51-119: PARDISO there, SuperLU here).
 
-    Factorises without pivoting in symmetric mode, so that the signs of diag(U)
-    give the inertia the caller needs to map `which` (partial_hevp.py:172-194)."""
+    The factorisation runs once on the host, without pivoting in symmetric mode, so that the signs
+    of diag(U) give the inertia the caller needs to map `which` (partial_hevp.py:172-194).  The
+    SOLVES run on the device (`device=True`, the default): the factors L, U and SuperLU's row /
+    column permutations become a TriangularChain (level-scheduled triangular solves on the whole
+    n x m block in HBM, algebra/hip/precond.py), so a solver iteration moves no block across PCIe.
+    `device=False` keeps the host solve (two block transfers per application), which is what the
+    first round shipped."""
 
-    def __init__(self, dtype=np.float64, pos_def=False):
+    def __init__(self, dtype=np.float64, pos_def=False, device=True):
         self._dtype = dtype
         self._lu = None
+        self._device = bool(device)
+        self._chain = None
 
     def analyse(self, a, sigma=0, b=None):
         a = scs.csc_matrix(a)
@@ -73,8 +80,24 @@ class SparseSymmetricSolver:
                                 options=dict(SymmetricMode=True))
         except Exception:
             raise RuntimeError('factorization failed (near singular matrix?)')
+        self._chain = None
+
+    def _device_chain(self):
+        """P_r A P_c = L U  =>  x = P_c U^-1 L^-1 P_r b: the scratch row r is row argsort(perm_r)[r] of b,
+        and goes to row argsort(perm_c)[r] of x."""
+        if self._chain is None:
+            from .precond import TriangularChain
+            lu = self._lu
+            lower = scs.tril(scs.csr_matrix(lu.L), -1, format='csr')        # SuperLU stores the unit diagonal
+            upper = scs.csr_matrix(lu.U)
+            self._chain = TriangularChain([(lower, True, True), (upper, False, False)], self._dtype,
+                                          np.argsort(lu.perm_r), np.argsort(lu.perm_c))
+        return self._chain
 
     def solve(self, b, x):
+        if self._device and not hasattr(b, 'comm'):
+            self._device_chain().solve(b, x)
+            return
         bh = b.data()
         x.fill(np.ascontiguousarray(self._lu.solve(np.ascontiguousarray(bh.T)).T, dtype=bh.dtype))
 

@@ -37,11 +37,13 @@ struct rlh_sptrsv {
   int dtype;
   int64_t n, nnz;                  // nnz: stored off-diagonal entries
   int lower, unit;
-  int64_t *rowptr;                 // device, n + 1
-  int32_t *cols;                   // device
-  void *vals;                      // device
-  void *dinv;                      // device: 1 / diagonal (nullptr: unit diagonal)
-  int32_t *lev_rows;               // device: the rows ordered by level
+  // device arrays in LEVEL order: position p holds row lev_rows[p]; its off-diagonal entries are
+  // cols / vals [rowptr[p], rowptr[p + 1]) (column = ORIGINAL row number), its 1 / diagonal dinv[p]
+  int64_t *rowptr;                 // n + 1
+  int32_t *cols;
+  void *vals;
+  void *dinv;                      // nullptr: unit diagonal
+  int32_t *lev_rows;               // the rows ordered by level
   std::vector<int64_t> lev_off;    // host: first position of every level in lev_rows, nlevels + 1
   int64_t *lev_off_d;              // device copy (the chain kernel walks several levels per launch)
   int64_t device_bytes;
@@ -198,97 +200,174 @@ __device__ __forceinline__ double neg_of(double a) { return -a; }
 __device__ __forceinline__ c32 neg_of(c32 a) { return c32{-a.re, -a.im}; }
 __device__ __forceinline__ c64 neg_of(c64 a) { return c64{-a.re, -a.im}; }
 
-// One row of one level for the 16-byte piece(s) of lane `lane` of the row's LPR lanes:
-// W[r][:] = (W[r][:] - sum_e vals[e] W[cols[e]][:]) * dinv[r].
+// Sum of the 16-byte pieces of the lanes that differ in the bits [lpr, lpr * sl) of the lane number
+// (the slices of one row).
+template <typename T, int EPL>
+__device__ __forceinline__ void reduce_slices(Piece<T, EPL> &acc, int lpr, int sl) {
+  constexpr int W = (int)(sizeof(T) * EPL / 4);
+  union U { Piece<T, EPL> p; int w[W]; };
+  for (int off = lpr; off < lpr * sl; off <<= 1) {
+    U a, b;
+    a.p = acc;
+#pragma unroll
+    for (int k = 0; k < W; ++k) b.w[k] = __shfl_xor(a.w[k], off);
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) acc.e[k] = add_of(acc.e[k], b.p.e[k]);
+  }
+}
+
+// One row of one level: W[r][:] = (W[r][:] - sum_e vals[e] W[cols[e]][:]) * dinv[r].  The row is worked
+// on by LPR x sl lanes of one wave: lane `piece` of LPR owns a 16-byte piece of the row (more than one
+// when the block has more than 64 pieces per row), slice `slice` of sl takes every sl-th entry -- the
+// gathers of a row are dependent loads (column index, then the referenced row), so the entries of a
+// long row are spread over lanes instead of being walked by one -- and the slices are summed by
+// lane shuffles.
 template <typename T, int LPR>
-__device__ __forceinline__ void trsv_row(int64_t r, int lane, const int64_t *__restrict__ rowptr,
+__device__ __forceinline__ void trsv_row(int64_t r, int64_t e0, int64_t e1, int64_t pos, int piece, int slice, int sl,
                                          const int32_t *__restrict__ cols, const T *__restrict__ vals,
                                          const T *__restrict__ dinv, T *W, int ldw, int ppr) {
   constexpr int EPL = 16 / (int)sizeof(T);
   using P = Piece<T, EPL>;
-  for (int p = lane; p < ppr; p += LPR) {                  // (one trip unless the block has more than 64 pieces per row)
-    T *wr = W + r * ldw + p * EPL;
-    P acc = *reinterpret_cast<const P *>(wr);
-    const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
-    for (int64_t e = e0; e < e1; e += 4) {
+  for (int p = piece; p - piece < ppr; p += LPR) {         // (one trip unless the block has more than 64 pieces per row)
+    const bool live = p < ppr;                             // (all lanes of the row stay in the shuffles)
+    const int pc = live ? p : ppr - 1;
+    T *wr = W + r * ldw + pc * EPL;
+    P acc;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) acc.e[k] = zero_of(T{});
+    if (slice == 0) acc = *reinterpret_cast<const P *>(wr);
+    for (int64_t e = e0 + slice; e < e1; e += 4 * (int64_t)sl) {
       int32_t c[4];
       T v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t ee = e + u < e1 ? e + u : e1 - 1;    // surplus slots repeat the last entry with value 0
-        c[u] = cols[ee];
-        v[u] = e + u < e1 ? neg_of(vals[ee]) : zero_of(T{});
+        const int64_t ee = e + (int64_t)u * sl;
+        const int64_t ec = ee < e1 ? ee : e;               // surplus slots repeat this lane's entry with value 0
+        c[u] = cols[ec];
+        v[u] = ee < e1 ? neg_of(vals[ec]) : zero_of(T{});
       }
       P x[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const P *>(W + (int64_t)c[u] * ldw + p * EPL);
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const P *>(W + (int64_t)c[u] * ldw + pc * EPL);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int k = 0; k < EPL; ++k) fma_acc(acc.e[k], v[u], x[u].e[k]);
     }
-    if (dinv) {
-      const T d = dinv[r];
+    if (sl > 1) reduce_slices<T, EPL>(acc, LPR, sl);
+    if (slice == 0 && live) {
+      if (dinv) {
+        const T d = dinv[pos];
 #pragma unroll
-      for (int k = 0; k < EPL; ++k) acc.e[k] = mul_of(acc.e[k], d);
+        for (int k = 0; k < EPL; ++k) acc.e[k] = mul_of(acc.e[k], d);
+      }
+      *reinterpret_cast<P *>(wr) = acc;
     }
-    *reinterpret_cast<P *>(wr) = acc;
   }
 }
 
-// One large dependency level: LPR lanes per row over as many workgroups as the level fills.
+// One large dependency level (positions [p0, p0 + nrows)): LPR x sl lanes per row over as many
+// workgroups as the level fills.
 template <typename T, int LPR>
-__global__ __launch_bounds__(256) void trsv_level_kernel(const int32_t *__restrict__ rows, int nrows,
+__global__ __launch_bounds__(256) void trsv_level_kernel(const int32_t *__restrict__ rows, int64_t p0, int nrows, int sl,
                                                          const int64_t *__restrict__ rowptr, const int32_t *__restrict__ cols,
                                                          const T *__restrict__ vals, const T *__restrict__ dinv,
                                                          T *W, int ldw, int ppr) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t rloc = gid / LPR;
-  if (rloc >= nrows) return;
-  trsv_row<T, LPR>(rows[rloc], (int)(gid % LPR), rowptr, cols, vals, dinv, W, ldw, ppr);
+  const int lpt = LPR * sl;                                // lanes per row (a power of two, at most 64)
+  const int64_t rloc = gid / lpt;
+  const int l = (int)(gid % lpt);
+  if (rloc >= nrows) return;                               // (whole groups of lpt lanes: a row's shuffles stay among its own lanes)
+  const int64_t pos = p0 + rloc;
+  trsv_row<T, LPR>(rows[pos], rowptr[pos], rowptr[pos + 1], pos, l % LPR, l / LPR, sl, cols, vals, dinv, W, ldw, ppr);
 }
+
+constexpr int kChainLevels = 8192;           // levels per launch of the chain kernel (their offsets sit in the LDS)
 
 // A run of SMALL consecutive levels [l0, l1) in ONE workgroup of 1024 threads: the levels follow each
 // other behind a workgroup barrier (the rows a level reads were written by waves of the same
 // workgroup: workgroup-scope release / acquire is what __syncthreads() provides), so a long chain of
 // tiny levels -- an FE matrix in a banded ordering has thousands of levels of a few dozen rows --
-// costs one launch instead of one launch per level.
+// costs one launch instead of one launch per level.  The critical path of such a chain is the
+// dependent loads of one level after the other: the offsets of the levels are copied to the LDS up
+// front, and a thread's row descriptor for the NEXT level (row, entry range: independent of the
+// solution) is fetched while the current level is computed.
 template <typename T, int LPR>
 __global__ __launch_bounds__(1024) void trsv_chain_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ lev_off,
-                                                          int l0, int l1, const int64_t *__restrict__ rowptr,
+                                                          int l0, int l1, int sl, const int64_t *__restrict__ rowptr,
                                                           const int32_t *__restrict__ cols, const T *__restrict__ vals,
                                                           const T *__restrict__ dinv, T *W, int ldw, int ppr) {
+  __shared__ int s_off[kChainLevels + 1];                  // first position of every level, relative to the run's first
   const int tid = threadIdx.x;
-  int64_t r0 = lev_off[l0];
-  for (int lev = l0; lev < l1; ++lev) {
-    const int64_t r1 = lev_off[lev + 1];
-    const int64_t tasks = (r1 - r0) * LPR;
-    for (int64_t t = tid; t < tasks; t += 1024)
-      trsv_row<T, LPR>(rows[r0 + t / LPR], (int)(t % LPR), rowptr, cols, vals, dinv, W, ldw, ppr);
+  const int lpt = LPR * sl;
+  const int64_t base = lev_off[l0];
+  for (int k = tid; k <= l1 - l0; k += 1024) s_off[k] = (int)(lev_off[l0 + k] - base);
+  __syncthreads();
+  const int my_row = tid / lpt, my_l = tid % lpt;          // this thread's first task of every level
+  struct Desc { int64_t pos, r, e0, e1; bool live; };
+  auto fetch = [&](int k) -> Desc {
+    Desc d;
+    d.live = k < l1 - l0 && my_row < s_off[k + 1] - s_off[k];
+    d.pos = base + (d.live ? s_off[k] + my_row : 0);
+    d.r = rows[d.pos];
+    d.e0 = rowptr[d.pos];
+    d.e1 = rowptr[d.pos + 1];
+    return d;
+  };
+  Desc next = fetch(0);
+  for (int k = 0; k < l1 - l0; ++k) {
+    const Desc cur = next;
+    next = fetch(k + 1);                                   // in flight during this level
+    if (cur.live) trsv_row<T, LPR>(cur.r, cur.e0, cur.e1, cur.pos, my_l % LPR, my_l / LPR, sl, cols, vals, dinv, W, ldw, ppr);
+    const int64_t tasks = (int64_t)(s_off[k + 1] - s_off[k]) * lpt;
+    for (int64_t t = tid + 1024; t < tasks; t += 1024) {   // levels of more than 1024 (row, lane) tasks
+      const int64_t pos = base + s_off[k] + t / lpt;
+      const int l = (int)(t % lpt);
+      trsv_row<T, LPR>(rows[pos], rowptr[pos], rowptr[pos + 1], pos, l % LPR, l / LPR, sl, cols, vals, dinv, W, ldw, ppr);
+    }
     __syncthreads();
-    r0 = r1;
   }
 }
 
-constexpr int64_t kChainTasks = 4096;      // a level of at most this many (row, lane) tasks counts as small
+// a level of at most this many (row, lane) tasks counts as small (RLH_SPTRSV_CHAIN_TASKS: tunable)
+static int64_t chain_tasks() {
+  const char *e = getenv("RLH_SPTRSV_CHAIN_TASKS");
+  return (e && *e) ? atoll(e) : 512;
+}
+
+// slices per row: enough lanes that a lane walks about four entries, within one wave
+static int slices_for(const rlh_sptrsv *t, int lpr) {
+  const double avg = t->n > 0 ? (double)t->nnz / (double)t->n : 0.0;
+  int sl = 1;
+  while (sl * 4 < avg && sl * 2 * lpr <= 64) sl *= 2;
+  const char *e = getenv("RLH_SPTRSV_SLICES");             // tunable
+  if (e && *e && atoi(e) > 0) {
+    sl = 1;
+    while (sl * 2 <= atoi(e) && sl * 2 * lpr <= 64) sl *= 2;
+  }
+  return sl;
+}
 
 template <typename T, int LPR>
 static void launch_levels_lpr(hipStream_t s, const rlh_sptrsv *t, T *W, int ldw, int ppr) {
   const int64_t nl = (int64_t)t->lev_off.size() - 1;
+  const int sl = slices_for(t, LPR);
+  const int64_t lpt = (int64_t)LPR * sl;
   int64_t lev = 0;
   while (lev < nl) {
     const int64_t nrows = t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev];
-    if (nrows * LPR > kChainTasks) {
-      const int64_t threads = nrows * LPR;
+    if (nrows * lpt > chain_tasks()) {
+      const int64_t threads = nrows * lpt;
       hipLaunchKernelGGL((trsv_level_kernel<T, LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
-                         t->lev_rows + t->lev_off[(size_t)lev], (int)nrows, t->rowptr, t->cols, (const T *)t->vals,
+                         t->lev_rows, t->lev_off[(size_t)lev], (int)nrows, sl, t->rowptr, t->cols, (const T *)t->vals,
                          (const T *)t->dinv, W, ldw, ppr);
       ++lev;
       continue;
     }
     int64_t end = lev + 1;                    // the run of small levels starting here
-    while (end < nl && (t->lev_off[(size_t)end + 1] - t->lev_off[(size_t)end]) * LPR <= kChainTasks) ++end;
-    hipLaunchKernelGGL((trsv_chain_kernel<T, LPR>), dim3(1), dim3(1024), 0, s, t->lev_rows, t->lev_off_d, (int)lev, (int)end,
+    while (end < nl && end - lev < kChainLevels &&
+           (t->lev_off[(size_t)end + 1] - t->lev_off[(size_t)end]) * lpt <= chain_tasks()) ++end;
+    hipLaunchKernelGGL((trsv_chain_kernel<T, LPR>), dim3(1), dim3(1024), 0, s, t->lev_rows, t->lev_off_d, (int)lev, (int)end, sl,
                        t->rowptr, t->cols, (const T *)t->vals, (const T *)t->dinv, W, ldw, ppr);
     lev = end;
   }
@@ -311,13 +390,14 @@ static void launch_levels(hipStream_t s, const rlh_sptrsv *t, T *W, int ldw, int
 
 // number of kernel launches launch_levels issues for an operator
 static int64_t count_launches(const rlh_sptrsv *t, int lpr) {
+  lpr *= slices_for(t, lpr);
   const int64_t nl = (int64_t)t->lev_off.size() - 1;
   int64_t n = 0, lev = 0;
   while (lev < nl) {
     ++n;
-    if ((t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr > kChainTasks) { ++lev; continue; }
-    ++lev;
-    while (lev < nl && (t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr <= kChainTasks) ++lev;
+    if ((t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr > chain_tasks()) { ++lev; continue; }
+    const int64_t first = lev++;
+    while (lev < nl && lev - first < kChainLevels && (t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr <= chain_tasks()) ++lev;
   }
   return n;
 }
@@ -443,6 +523,21 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     for (int64_t i = 0; i < n; ++i) order[(size_t)next[(size_t)level[(size_t)i]]++] = (int32_t)i;   // ascending rows inside a level
   }
   t->nnz = (int64_t)cols.size();
+  {
+    // re-store the entries (and the inverse diagonal) in level order: the rows of a level are then one
+    // contiguous range of positions, their entries one contiguous run
+    std::vector<int64_t> rp2((size_t)n + 1, 0);
+    std::vector<int32_t> cols2(cols.size());
+    std::vector<T> vals2(vals.size()), dinv2(dinv.size());
+    int64_t w = 0;
+    for (int64_t p = 0; p < n; ++p) {
+      const int64_t r = order[(size_t)p];
+      for (int64_t e = rp[(size_t)r]; e < rp[(size_t)r + 1]; ++e, ++w) { cols2[(size_t)w] = cols[(size_t)e]; vals2[(size_t)w] = vals[(size_t)e]; }
+      rp2[(size_t)p + 1] = w;
+      if (!t->unit) dinv2[(size_t)p] = dinv[(size_t)r];
+    }
+    rp.swap(rp2); cols.swap(cols2); vals.swap(vals2); dinv.swap(dinv2);
+  }
   RLH_HIP(hipMalloc((void **)&t->rowptr, (size_t)(n + 1) * sizeof(int64_t)));
   RLH_HIP(hipMemcpy(t->rowptr, rp.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
   RLH_HIP(hipMalloc((void **)&t->cols, std::max<size_t>(cols.size(), 1) * sizeof(int32_t)));

@@ -46,7 +46,65 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
     return gj < msplit ? Out + (int64_t)gj * ldo : Out2 + (int64_t)(gj - msplit) * ldo2;
   };
   const int64_t stride = (int64_t)gridDim.x * 256 * RV;
-  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV; row < n; row += stride) {
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV; row - (int64_t)(threadIdx.x & 63) * RV < n; row += stride) {
+    // every row group of the wave is complete (wave-uniform): straight-line loads, the columns of X
+    // in a two-stage register pipeline -- the loads of the next kUnrollK columns are in flight during
+    // the FMAs of the current ones (with one predicate per load the compiler put every load behind a
+    // branch and an s_waitcnt vmcnt(0) in front of the FMAs: nothing overlapped inside a wave)
+    const int64_t wave_row0 = row - (int64_t)(threadIdx.x & 63) * RV;
+    if (RV > 1 && wave_row0 + 64 * RV <= n) {
+      T acc[RV][JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+#pragma unroll
+        for (int r = 0; r < RV; ++r) acc[r][j] = zero_of(T{});
+        if (BETA && j < jv) {
+          const V o = *reinterpret_cast<const V *>(out_col(j) + row);
+#pragma unroll
+          for (int r = 0; r < RV; ++r) acc[r][j] = o.e[r];
+        }
+      }
+      auto accumulate_fast = [&](const T *__restrict__ S, int64_t lds_, int kk, int qrow0) {
+        if (kk <= 0) return;
+        V xa[kUnrollK], xb[kUnrollK];
+        auto load = [&](V (&x)[kUnrollK], int i) {
+#pragma unroll
+          for (int u = 0; u < kUnrollK; ++u) {
+            const int col = (i + u) < kk ? (i + u) : (kk - 1);       // Q rows >= kk are zero
+            x[u] = *reinterpret_cast<const V *>(S + row + (int64_t)col * lds_);
+          }
+        };
+        auto fma = [&](const V (&x)[kUnrollK], int i) {
+#pragma unroll
+          for (int u = 0; u < kUnrollK; ++u)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+              const T q = Qp[(qrow0 + i + u) * ldq + j];
+#pragma unroll
+              for (int r = 0; r < RV; ++r) fma_acc(acc[r][j], x[u].e[r], q);
+            }
+        };
+        load(xa, 0);
+        for (int i = 0; i < kk; i += 2 * kUnrollK) {
+          load(xb, i + kUnrollK < kk ? i + kUnrollK : i);
+          fma(xa, i);
+          load(xa, i + 2 * kUnrollK < kk ? i + 2 * kUnrollK : i);
+          if (i + kUnrollK < kk) fma(xb, i + kUnrollK);
+        }
+      };
+      accumulate_fast(X, ldx, k, 0);
+      accumulate_fast(X2, ldx2, k2, kpad);
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+        if (j < jv) {
+          V o;
+#pragma unroll
+          for (int r = 0; r < RV; ++r) o.e[r] = acc[r][j];
+          *reinterpret_cast<V *>(out_col(j) + row) = o;
+        }
+      continue;
+    }
+    if (row >= n) continue;
     const bool whole = row + RV <= n;                // the last lane group of an n not divisible by RV
     T acc[RV][JT];
 #pragma unroll

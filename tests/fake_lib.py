@@ -110,11 +110,16 @@ class FakeLib:
         return 0
 
     def rlh_h2d(self, d, h, nbytes):
+        if int(nbytes) > 4096:
+            self._count('block_transfer')
         ctypes.memmove(_addr(d), _addr(h), int(nbytes))
         return 0
 
     rlh_d2h = rlh_h2d
-    rlh_d2d = rlh_h2d
+
+    def rlh_d2d(self, d, s, nbytes):
+        ctypes.memmove(_addr(d), _addr(s), int(nbytes))
+        return 0
 
     def rlh_fetch(self, h, d, nbytes):
         self._count('fetch')
@@ -123,6 +128,8 @@ class FakeLib:
         return 0
 
     def rlh_copy2d(self, dst, dpitch, src, spitch, width, rows, kind):
+        if kind != 2:
+            self._count('block_transfer')         # a block crossing the host / device boundary
         d, s = _addr(dst), _addr(src)
         for r in range(int(rows)):
             ctypes.memmove(d + r * dpitch, s + r * spitch, int(width))

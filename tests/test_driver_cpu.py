@@ -407,3 +407,28 @@ def test_batched_and_unbatched_drivers_agree(monkeypatch):
         out.append((lmd[:6], partial_hevp.last['iterations']))
     assert np.allclose(out[0][0], out[1][0], rtol=1e-12)
     assert abs(out[0][1] - out[1][1]) <= max(2, out[1][1] // 20)
+
+
+def test_shift_invert_moves_no_block_across_pcie(fake, golden_dir):
+    """Shift-invert with the solves on the device (SuperLU factors + permutations as a chain of
+    level-scheduled triangular solves): the reference's known answer for config 1 (17 iterations, six
+    eigenvalues) with no block upload / download between the set-up and the final read-back -- and the
+    same eigenvalues with the host solve, which moves two blocks per application."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip.host_ops import SparseSymmetricSolver
+    from oracle.sparse import lap3d
+    k = known(golden_dir)['hevp_lap30_si6']
+    A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
+    out = {}
+    for device in (True, False):
+        solver = SparseSymmetricSolver(device=device)
+        solver.analyse(A, 0.0)
+        solver.factorize()
+        np.random.seed(1)
+        before = fake.calls.get('block_transfer', 0)
+        lmd, x, status = partial_hevp(solver, which=6, tol=1e-6, verb=-1)
+        out[device] = (lmd, partial_hevp.last['iterations'], fake.calls.get('block_transfer', 0) - before)
+        assert status == 0 and np.allclose(lmd[:6], k['eigenvalues'], rtol=1e-10)
+    assert abs(out[True][1] - 17) <= 3
+    assert out[True][2] <= 4                              # start block in, eigenvectors out: nothing per iteration
+    assert out[False][2] >= 2 * out[False][1]             # the host solve: two transfers per application
