@@ -226,7 +226,25 @@ class ShardedVectors(Vectors):
 
     def dots(self, other, transp=False):
         if transp:
-            raise NotImplementedError('transposed dots of row-sharded vectors')
+            # per-ROW sums over the selected vectors (dense_cublas.py:175-221, used by
+            # truncated_svd.py:183,195 and lra.py:321): every rank computes its own rows on the device,
+            # the global vector of length n is assembled on every rank by one all-gather
+            loc = Vectors.dots(self, other, transp=True)
+            c = self._comm
+            tt = c.torch
+            maxloc = int(np.max(np.diff(self._offsets)))
+            send = np.zeros((maxloc,), dtype=self.data_type())
+            send[:loc.shape[0]] = loc
+            st = tt.from_numpy(send.view(_REAL[self.data_type()]))
+            if c.on_device:
+                st = st.to(c.device)
+            parts = [tt.empty_like(st) for _ in range(c.size)]
+            c.dist.all_gather(parts, st, group=c.group)
+            out = np.zeros((self._gdim,), dtype=self.data_type())
+            for p in range(c.size):
+                r0, r1 = self._offsets[p], self._offsets[p + 1]
+                out[r0:r1] = parts[p].cpu().numpy().view(self.data_type())[:r1 - r0]
+            return out
         m = self.nvec()
         if m == 0:
             return np.zeros((0,), dtype=self.data_type())

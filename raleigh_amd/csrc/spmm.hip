@@ -146,11 +146,12 @@ static int launch_spmm_t(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, i
   const int64_t need = ((h->n_slices + slices_per_block - 1) / slices_per_block + 7) / 8 * 8;
   if (nb > need) nb = need;
   nb = (nb + 7) / 8 * 8;
-  if (cheb)
-    hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT, true>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr,
-                       h->cols, (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
-                       chunk < 1 ? 1 : chunk, ntiles, tiles_per_block, *cheb);
-  else
+  if (cheb) {
+    if constexpr (JT < 32)         // (32 accumulators + the fused epilogue spill: the fused step takes tiles of 16)
+      hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT, true>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr,
+                         h->cols, (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
+                         chunk < 1 ? 1 : chunk, ntiles, tiles_per_block, *cheb);
+  } else
     hipLaunchKernelGGL((sell_spmm_kernel<T, JT, TT, false>), dim3((unsigned)nb), dim3(256), 0, c.stream, h->slice_ptr,
                        h->cols, (const T *)h->vals, h->n_rows, h->n_slices, X, ldx, n_own, H, ldh, Y, ldy, (int)m,
                        chunk < 1 ? 1 : chunk, ntiles, tiles_per_block, ChebArgs<T>{});
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(1024) void well_spmm_kernel(const WellMeta *__restr
         boff += (unsigned)F * (unsigned)sizeof(T);
       }
     };
-    if constexpr (PACK || EPL == 1) {
+    if constexpr (PACK || EPL == 1 || (CHEB && sizeof(T) == 8)) {     // (the fp64 fused step spilled 52 bytes with two sets)
       // one register set only (the element-wise staging of unaligned layouts needs SMAX slots per
       // set): the loads of step s + 1 are in flight during the arithmetic of step s
       stage_load(0, stA);
@@ -723,7 +724,7 @@ static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ld
   const int jt_cap = env_int("RLH_SPMM_JT", 16);        // vectors per lane tile (tunable; 16 measured best at m = 32 fp64)
   if (m <= 4 || jt_cap <= 4) return launch_spmm<T, 4>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   if (m <= 8 || jt_cap <= 8) return launch_spmm<T, 8>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
-  if (m <= 16 || JTMAX == 16 || jt_cap <= 16) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+  if (m <= 16 || JTMAX == 16 || jt_cap <= 16 || cheb) return launch_spmm<T, 16>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   return launch_spmm<T, (JTMAX == 32 ? 32 : 16)>(h, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
 }
 

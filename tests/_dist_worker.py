@@ -45,6 +45,22 @@ def main():
         assert np.linalg.norm(d - ops.dots(x[2:5], x[2:5])) < tol * np.linalg.norm(d)
         X.select(m)
         assert np.array_equal(X.data(), x)
+        # transposed dots: per-row sums over the vectors, assembled on every rank
+        X.select(4, 1)
+        Y.select(4)
+        dtr = X.dots(Y, transp=True)
+        assert dtr.shape == (n,)
+        assert np.linalg.norm(dtr - np.sum(np.conj(y[:4]) * x[1:5], axis=0)) < 10 * tol * np.linalg.norm(dtr)
+        X.select(m)
+        Y.select(k)
+        # a batch of stacked Grams and dots: one all-reduce, one fetch
+        rb = X.reduction_batch()
+        rb.gram([X], [Y, X])
+        rb.dots(Y, Y)
+        g2, d2 = rb.run()
+        assert np.linalg.norm(g2[:k] - ops.gram(x, y)) < tol * np.linalg.norm(g2[:k])
+        assert np.linalg.norm(g2[k:] - ops.gram(x, x)) < tol * np.linalg.norm(g2[k:])
+        assert np.linalg.norm(d2 - ops.dots(y, y)) < tol * np.linalg.norm(d2)
         q = rng.standard_normal((m, k)).astype(dt)
         W = Y.new_vectors(k)
         X.multiply(q, W)

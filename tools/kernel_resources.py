@@ -24,4 +24,4 @@ def main(files):
                 g(r'Occupancy \[waves/SIMD\]'), g(r'LDS Size \[bytes/block\]')))
 
 if __name__ == '__main__':
-    main(sys.argv[1:] or ['gram', 'update', 'spmm', 'spmm_wide_s', 'spmm_wide_d', 'spmm_wide_c', 'spmm_wide_z', 'dense'])
+    main(sys.argv[1:] or ['gram', 'update', 'spmm', 'spmm_wide_s', 'spmm_wide_d', 'spmm_wide_c', 'spmm_wide_z', 'sptrsv', 'dense'])
