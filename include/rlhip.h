@@ -282,6 +282,17 @@ int rlh_dense_apply(int dtype, int64_t M, int64_t N, const void *A, int64_t lda,
                     int order, int transp, int64_t m, const void *X,
                     int64_t ldx, void *Y, int64_t ldy);
 
+/* The same product with a rank-one correction folded into its epilogue (no further pass over Y):
+ *   Y[:, j] = Op(A) X[:, j] - c[j] * u,   u, c DEVICE arrays (u of the output dimension, NULL = a
+ * vector of ones; c of m coefficients; both NULL = rlh_dense_apply).  This is how the mean shift
+ * of the PCA operator A_s = A - e a^T is applied (raleigh/interfaces/partial_svd.py:258-291 removes
+ * it from the intermediate block with two dot + add passes per product): c is produced on the
+ * device by rlh_gram / rlh_dots with d_out, so one operator application is two GEMMs and two small
+ * reductions with no host synchronisation. */
+int rlh_dense_apply_r1(int dtype, int64_t M, int64_t N, const void *A, int64_t lda, int order,
+                       int transp, int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy,
+                       const void *d_u, const void *d_c);
+
 /* ---- profiling aid: HIP-event time of the last `count` kernels ---- */
 int rlh_timer_start(void);
 int rlh_timer_stop(float *milliseconds);

@@ -87,6 +87,7 @@ SIGNATURES = {
     'rlh_sptrsv_solve_chain': [_int, _p, _p, _p, _i64, _p, _i64, _p, _i64],
     'rlh_sptrsv_destroy': [_p],
     'rlh_dense_apply': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64],
+    'rlh_dense_apply_r1': [_int, _i64, _i64, _p, _i64, _int, _int, _i64, _p, _i64, _p, _i64, _p, _p],
     'rlh_timer_start': [],
     'rlh_timer_stop': [ctypes.POINTER(ctypes.c_float)],
 }

@@ -95,6 +95,12 @@ class Matrix:
         return Vectors(dim, nv, self.data_type())
 
     def apply(self, x, y, transp=False):
+        self.apply_r1(x, y, transp)
+
+    def apply_r1(self, x, y, transp=False, u=None, c=None):
+        """y = Op(A) x - u c^T with the rank-one term folded into the product's epilogue (rlh_dense_apply_r1):
+        `c` a device pointer to x.nvec() coefficients (e.g. written by `coefficients_into`), `u` a Vectors
+        window of ONE vector of y's dimension or None for a vector of ones.  c None: the plain product."""
         if x.data_type() != self._dtype or y.data_type() != self._dtype:
             raise ValueError('Matrix and vectors data types differ')
         m, n = self._shape
@@ -107,7 +113,20 @@ class Matrix:
         k = x.nvec()
         if k != y.nvec():
             raise ValueError('Numbers of input and output vectors differ')
-        _lib.check(_lib.lib().rlh_dense_apply(
+        if u is not None and (u.nvec() != 1 or u.dimension() != y.dimension() or c is None):
+            raise ValueError('the rank-one term needs one vector of the output dimension and coefficients')
+        _lib.check(_lib.lib().rlh_dense_apply_r1(
             self._code, m, n, self.data_ptr(), self._lda,
             0 if self._order == 'C_CONTIGUOUS' else 1, 1 if transp else 0,
-            k, x.data_ptr(), x.ld(), y.data_ptr(), y.ld()))
+            k, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(),
+            None if u is None else u.data_ptr(), c))
+
+
+def coefficients_into(buf_ptr, x, w):
+    """buf[j] = <x_j, w> = w^H x_j for the selected vectors of x and the ONE vector w, written to DEVICE
+    memory at buf_ptr without a host synchronisation (rlh_gram with a device output): the coefficients
+    of a rank-one epilogue."""
+    if w.nvec() != 1 or w.dimension() != x.dimension():
+        raise ValueError('one vector of the same dimension is needed')
+    n = getattr(x, 'local_dimension', x.dimension)()
+    _lib.check(_lib.lib().rlh_gram(x._code, n, x.nvec(), x.data_ptr(), x.ld(), 1, w.data_ptr(), w.ld(), buf_ptr, None))

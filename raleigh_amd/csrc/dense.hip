@@ -25,7 +25,27 @@ struct DenseArgs {
   const void *X; int64_t ldx;
   void *Y; int64_t ldy;
   int m;
+  // rank-one epilogue Y[i, v] -= u[i] * c[v] (u == nullptr: a vector of ones), folded into the tile
+  // store / the split-K reduction: the mean-shift corrections of the PCA operator
+  // (raleigh/interfaces/partial_svd.py:258-291) without a further pass over the block
+  const void *r1_u, *r1_c;
 };
+
+// y - u c for the element types (real: plain product; complex: u[i] * c[v], no conjugation)
+__device__ __forceinline__ float r1_sub(float y, float u, float c) { return y - u * c; }
+__device__ __forceinline__ double r1_sub(double y, double u, double c) { return y - u * c; }
+__device__ __forceinline__ c32 r1_sub(c32 y, c32 u, c32 c) { const c32 p = mul_of(u, c); return c32{y.re - p.re, y.im - p.im}; }
+__device__ __forceinline__ c64 r1_sub(c64 y, c64 u, c64 c) { const c64 p = mul_of(u, c); return c64{y.re - p.re, y.im - p.im}; }
+__device__ __forceinline__ float one_of(float) { return 1.f; }
+__device__ __forceinline__ double one_of(double) { return 1.0; }
+__device__ __forceinline__ c32 one_of(c32) { return c32{1.f, 0.f}; }
+__device__ __forceinline__ c64 one_of(c64) { return c64{1.0, 0.0}; }
+template <typename T>
+__device__ __forceinline__ T r1_apply(const DenseArgs &a, T y, int64_t i, int v) {
+  if (!a.r1_c) return y;
+  const T u = a.r1_u ? ((const T *)a.r1_u)[i] : one_of(T{});
+  return r1_sub(y, u, ((const T *)a.r1_c)[v]);
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -180,19 +200,225 @@ __global__ __launch_bounds__(256) void dense_mfma_f32_kernel(DenseArgs a, float 
       for (int r = 0; r < 16; ++r) {
         const int v = v0 + vcol0 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int64_t i = i0 + mrow0 + tm * 32 + (lane & 31);
-        if (v < a.m && i < a.ny) out[i + (int64_t)v * ldo] = acc[tn][tm][r];
+        if (v < a.m && i < a.ny) out[i + (int64_t)v * ldo] = part ? acc[tn][tm][r] : r1_apply<float>(a, acc[tn][tm][r], i, v);
       }
 }
 
 __global__ __launch_bounds__(256) void dense_splitk_reduce(const float *__restrict__ part, int splits, int64_t ny, int m,
-                                                           float *__restrict__ Y, int64_t ldy) {
+                                                           float *__restrict__ Y, int64_t ldy, DenseArgs a) {
   const int v = blockIdx.y;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ny; i += stride) {
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += part[((int64_t)z * m + v) * ny + i];
-    Y[i + (int64_t)v * ldy] = s;
+    Y[i + (int64_t)v * ldy] = r1_apply<float>(a, s, i, v);
   }
+}
+
+// Second-generation fp32 kernel (RLH_DENSE_KERNEL=2, the default): the same tiling -- C^T tile of BN
+// vectors x 128 output rows per 256-thread workgroup, K split over gridDim.z -- with
+//  * an LDS image [row][BK floats] whose 8-byte units are XOR-swizzled with the row number
+//    (unit u of row r sits at position u ^ ((r >> 1) & (BK / 2 - 1))): the tiles go in with ONE
+//    ds_write_b128 per 16-byte global piece (the 33-float padding of the first kernel forced four
+//    ds_write_b32) and the MFMA fragments come out with ONE conflict-free ds_read_b64 per operand tile and
+//    TWO k-steps: lanes 0-31 read the unit (k, k + 1), lanes 32-63 the unit (k + 2, k + 3) of their row
+//    -- the k order inside four consecutive k is permuted identically for both operands, which a sum over
+//    k does not see;
+//  * BK = 16 as well as 32: half the LDS per workgroup, so four workgroups instead of two share a CU and
+//    a SIMD always has a wave with an MFMA ready while another waits at its barrier (PMC of the first
+//    kernel at 20000 x 20000 x 128: MFMA pipes 76 % busy, 1.7 waves per SIMD);
+//  * column-major tiles (the transposed product of a row-major matrix) transposed 4 x 4 in registers on
+//    the way in, so they too are written with ds_write_b128, conflict-free.
+template <int BN, int BK, bool A_KC>
+__global__ __launch_bounds__(256, (BK == 16 ? (A_KC ? 4 : 3) : 2)) void dense_mfma2_f32_kernel(DenseArgs a, float *__restrict__ part, int64_t kchunk) {
+  constexpr int MR = 128;
+  constexpr int WGN = (BN >= 64) ? 2 : 1;          // waves along the vector dimension
+  constexpr int WGM = 4 / WGN;                     // waves along the output-row dimension
+  constexpr int TN = BN / WGN / 32, TM = MR / WGM / 32;
+  constexpr int ROWB = BK * 4;                     // bytes per LDS row
+  constexpr int UM = BK / 2 - 1;                   // swizzle mask on 8-byte units
+  constexpr int QPR = BK / 4;                      // 16-byte pieces per row
+  constexpr int NBLK = (MR / 4) * (BK / 4);        // 4 x 4 blocks of a column-major tile (A_KC false)
+  constexpr int A_UNITS = A_KC ? MR * BK / 4 / 256 : 4;   // 16-byte pieces per thread and K step
+  constexpr int B_UNITS = (BN * BK / 4 + 255) / 256;
+  static_assert(TN >= 1 && TM >= 1 && A_UNITS >= 1 && NBLK <= 256, "tile split");
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+
+  __shared__ __attribute__((aligned(16))) char ldsA[2][MR * ROWB];
+  __shared__ __attribute__((aligned(16))) char ldsB[2][BN * ROWB];
+
+  const float *__restrict__ A = (const float *)a.A;
+  const float *__restrict__ X = (const float *)a.X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int64_t i0 = (int64_t)blockIdx.x * MR;
+  const int v0 = blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk) < a.nx ? (kbeg + kchunk) : a.nx;
+
+  // byte offset of the 16-byte piece (k .. k + 3, k a multiple of 4) of row r, and whether its two
+  // 8-byte units are stored in swapped order
+  auto piece_off = [](int r, int kq4) -> int { return r * ROWB + ((((kq4 >> 1) ^ ((r >> 1) & UM)) >> 1) << 4); };
+  auto piece_swap = [](int r) -> bool { return ((r >> 1) & 1) != 0; };
+
+  f4 ra[A_UNITS], rb[B_UNITS];
+  auto load_tiles = [&](int64_t k0, bool tail) {
+    if constexpr (A_KC) {          // piece = 4 consecutive k of one output row
+#pragma unroll
+      for (int q = 0; q < A_UNITS; ++q) {
+        const int u = tid + q * 256;
+        const int r = u / QPR, kq = (u % QPR) * 4;
+        int64_t i = i0 + r;
+        i = i < a.ny ? i : a.ny - 1;                 // clamped rows are computed but never stored
+        const int64_t k = k0 + kq;
+        f4 v = *(const f4 *)(A + i * a.lda + ((!tail || k + 3 < a.lda) ? k : 0));
+        if (tail) {
+          if (k + 0 >= kend) v[0] = 0.f;
+          if (k + 1 >= kend) v[1] = 0.f;
+          if (k + 2 >= kend) v[2] = 0.f;
+          if (k + 3 >= kend) v[3] = 0.f;
+        }
+        ra[q] = v;
+      }
+    } else {                       // piece q of the thread = rows rq .. rq + 3 at k = kq + q: a 4 x 4 block
+      const int blk = NBLK >= 256 ? tid : tid % NBLK;   // (BK = 16: 128 blocks, the upper half of the threads repeats them)
+      const int kq = (blk / (MR / 4)) * 4, rq = (blk % (MR / 4)) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int64_t i = i0 + rq;
+        i = (i + 3 < a.lda) ? i : 0;
+        const int64_t k = k0 + kq + q;
+        f4 v = *(const f4 *)(A + ((!tail || k < kend) ? k : kbeg) * a.lda + i);
+        if (tail && k >= kend) v = f4{0.f, 0.f, 0.f, 0.f};
+        ra[q] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < B_UNITS; ++q) {
+      const int u = tid + q * 256;
+      const int c = (u / QPR) % BN, kq = (u % QPR) * 4;
+      int vc = v0 + c;
+      vc = vc < a.m ? vc : a.m - 1;
+      const int64_t k = k0 + kq;
+      f4 v = *(const f4 *)(X + (int64_t)vc * a.ldx + ((!tail || k + 3 < a.ldx) ? k : 0));
+      if (tail) {
+        if (k + 0 >= kend) v[0] = 0.f;
+        if (k + 1 >= kend) v[1] = 0.f;
+        if (k + 2 >= kend) v[2] = 0.f;
+        if (k + 3 >= kend) v[3] = 0.f;
+      }
+      rb[q] = v;
+    }
+  };
+  auto put = [&](char *base, int r, int kq, f4 v) {
+    const f4 w = piece_swap(r) ? f4{v[2], v[3], v[0], v[1]} : v;
+    *reinterpret_cast<f4 *>(base + piece_off(r, kq)) = w;
+  };
+  auto store_tiles = [&](int buf) {
+    char *la = ldsA[buf], *lb = ldsB[buf];
+    if constexpr (A_KC) {
+#pragma unroll
+      for (int q = 0; q < A_UNITS; ++q) {
+        const int u = tid + q * 256;
+        put(la, u / QPR, (u % QPR) * 4, ra[q]);
+      }
+    } else {
+      const int blk = NBLK >= 256 ? tid : tid % NBLK;
+      const int kq = (blk / (MR / 4)) * 4, rq = (blk % (MR / 4)) * 4;
+      if (NBLK >= 256 || tid < NBLK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)                  // row rq + j: its four k from the four loaded pieces
+          put(la, rq + j, kq, f4{ra[0][j], ra[1][j], ra[2][j], ra[3][j]});
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < B_UNITS; ++q) {
+      const int u = tid + q * 256;
+      if (BN * QPR >= 256 || u < BN * QPR) put(lb, (u / QPR) % BN, (u % QPR) * 4, rb[q]);
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int mrow0 = wm * (MR / WGM), vcol0 = wn * (BN / WGN);
+  // byte offsets of this lane's fragment rows (k-independent part) and their swizzle keys
+  int offA[TM], keyA[TM], offB[TN], keyB[TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) { const int r = mrow0 + tm * 32 + fr; offA[tm] = r * ROWB; keyA[tm] = (r >> 1) & UM; }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) { const int r = vcol0 + tn * 32 + fr; offB[tn] = r * ROWB; keyB[tn] = (r >> 1) & UM; }
+
+  int buf = 0;
+  if (kbeg < kend) {
+    load_tiles(kbeg, kbeg + BK > kend);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK < kend);
+    if (more) {
+      if (k0 + 2 * BK > kend) load_tiles(k0 + BK, true); else load_tiles(k0 + BK, false);
+    }
+    const char *la = ldsA[buf], *lb = ldsB[buf];
+    // Fragments in two register sets: the ds_reads of group g + 1 are issued BEFORE the eight MFMAs of
+    // group g (the scheduling barriers keep them there: left alone the compiler put each group's reads
+    // behind the previous group's MFMAs and waited for them at once -- one LDS latency per 512 MFMA
+    // cycles with nothing else for the wave to issue).  Four k per group: units 2 g (lanes 0-31) and
+    // 2 g + 1 (lanes 32-63).
+    f2 fxa[TN], faa[TM], fxb[TN], fab[TM];
+    auto frag_read = [&](int g, f2 (&fx)[TN], f2 (&fa)[TM]) {
+      const int u = 2 * g + fh;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) fx[tn] = *reinterpret_cast<const f2 *>(lb + offB[tn] + ((u ^ keyB[tn]) << 3));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) fa[tm] = *reinterpret_cast<const f2 *>(la + offA[tm] + ((u ^ keyA[tm]) << 3));
+    };
+    auto frag_mfma = [&](const f2 (&fx)[TN], const f2 (&fa)[TM]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fx[tn][h], fa[tm][h], acc[tn][tm], 0, 0, 0);
+    };
+    frag_read(0, fxa, faa);
+#pragma unroll
+    for (int g = 0; g < BK / 4; g += 2) {
+      frag_read(g + 1, fxb, fab);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mfma(fxa, faa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < BK / 4) frag_read(g + 2, fxa, faa);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mfma(fxb, fab);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D[v][i]: col (lane & 31) = output row i, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = vector v
+  float *__restrict__ out = part ? part + (int64_t)blockIdx.z * a.m * a.ny : (float *)a.Y;
+  const int64_t ldo = part ? a.ny : a.ldy;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int v = v0 + vcol0 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t i = i0 + mrow0 + tm * 32 + (lane & 31);
+        if (v < a.m && i < a.ny) out[i + (int64_t)v * ldo] = part ? acc[tn][tm][r] : r1_apply<float>(a, acc[tn][tm][r], i, v);
+      }
 }
 
 // Generic VALU GEMM for f64 / complex: 64 x 64 output tile, BK = 16, 4 x 4 micro-tile per thread.
@@ -253,7 +479,7 @@ __global__ __launch_bounds__(256) void dense_valu_kernel(DenseArgs a) {
     for (int p = 0; p < 4; ++p) {
       const int64_t i = i0 + ti * 4 + p;
       const int v = v0 + tv * 4 + q;
-      if (i < a.ny && v < a.m) Y[i + (int64_t)v * a.ldy] = acc[p][q];
+      if (i < a.ny && v < a.m) Y[i + (int64_t)v * a.ldy] = r1_apply<T>(a, acc[p][q], i, v);
     }
 }
 
@@ -288,7 +514,41 @@ static int launch_mfma(const DenseArgs &a) {
     int64_t nb = (a.ny + 255) / 256;
     if (nb > 64) nb = 64;
     hipLaunchKernelGGL(dense_splitk_reduce, dim3((unsigned)nb, (unsigned)a.m), dim3(256), 0, c.stream, part,
-                       (int)splits, a.ny, a.m, (float *)a.Y, a.ldy);
+                       (int)splits, a.ny, a.m, (float *)a.Y, a.ldy, a);
+    RLH_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+template <int BN, int BK>
+static int launch_mfma2(const DenseArgs &a) {
+  Context &c = ctx();
+  constexpr int MR = 128;
+  const int64_t bx = (a.ny + MR - 1) / MR, by = (a.m + BN - 1) / BN;
+  // split K until every CU has a few workgroups (the M x m output alone gives too few): BK = 16 leaves
+  // room for four resident workgroups per CU, BK = 32 for two
+  const int target = env_int_d("RLH_DENSE_WG_PER_CU", BK == 16 ? 8 : 8);
+  int64_t splits = ((int64_t)c.num_cu * target + bx * by - 1) / (bx * by);
+  const int64_t max_by_k = (a.nx + 32 * 16 - 1) / (32 * 16);           // at least 512 k per split
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits > 16) splits = 16;
+  while (splits > 1 && (size_t)splits * a.m * a.ny * sizeof(float) > kWorkspaceBytes) --splits;
+  if (splits < 1) splits = 1;
+  int64_t kchunk = ((a.nx + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.nx + kchunk - 1) / kchunk;
+  if (splits < 1) { splits = 1; kchunk = 32; }
+  float *part = splits > 1 ? (float *)c.work : nullptr;
+  dim3 grid((unsigned)bx, (unsigned)by, (unsigned)splits);
+  if (a.a_kcontig)
+    hipLaunchKernelGGL((dense_mfma2_f32_kernel<BN, BK, true>), grid, dim3(256), 0, c.stream, a, part, kchunk);
+  else
+    hipLaunchKernelGGL((dense_mfma2_f32_kernel<BN, BK, false>), grid, dim3(256), 0, c.stream, a, part, kchunk);
+  RLH_HIP(hipGetLastError());
+  if (splits > 1) {
+    int64_t nb = (a.ny + 255) / 256;
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL(dense_splitk_reduce, dim3((unsigned)nb, (unsigned)a.m), dim3(256), 0, c.stream, part,
+                       (int)splits, a.ny, a.m, (float *)a.Y, a.ldy, a);
     RLH_HIP(hipGetLastError());
   }
   return 0;
@@ -304,6 +564,15 @@ static int dense_impl(const DenseArgs &a) {
               (a.lda % 4 == 0) && (a.ldx % 4 == 0) && a.lda >= 4 && a.ldx >= 4 && a.nx > 0;
   }
   if constexpr (DT == RLH_S) {
+    // measured at 20000 x 20000 x 128: tiles with k contiguous 1.13 ms (first kernel) / 1.20 ms (second),
+    // column-major tiles 1.11 ms / 1.04 ms (RLH_DENSE_KERNEL=1|2 forces one: tunable)
+    const int kern = env_int_d("RLH_DENSE_KERNEL", a.a_kcontig ? 1 : 2);
+    if (mfma_ok && kern == 2) {
+      const int bk = env_int_d("RLH_DENSE_BK", 16);                  // tunable: 16 or 32
+      if (a.m > 64) return bk == 32 ? launch_mfma2<128, 32>(a) : launch_mfma2<128, 16>(a);
+      if (a.m > 32) return bk == 32 ? launch_mfma2<64, 32>(a) : launch_mfma2<64, 16>(a);
+      return bk == 32 ? launch_mfma2<32, 32>(a) : launch_mfma2<32, 16>(a);
+    }
     if (mfma_ok) {
       static const int mr = env_int_d("RLH_DENSE_MR", 128);
       if (a.m > 64) return mr == 64 ? launch_mfma<64, 128>(a) : launch_mfma<128, 128>(a);
@@ -324,9 +593,20 @@ static int dense_impl(const DenseArgs &a) {
 
 using namespace rlh;
 
+extern "C" int rlh_dense_apply_r1(int dtype, int64_t M, int64_t N, const void *A, int64_t lda, int order, int transp,
+                                  int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy, const void *d_u,
+                                  const void *d_c);
+
 extern "C" int rlh_dense_apply(int dtype, int64_t M, int64_t N, const void *A, int64_t lda, int order, int transp,
                                int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy) {
+  return rlh_dense_apply_r1(dtype, M, N, A, lda, order, transp, m, X, ldx, Y, ldy, nullptr, nullptr);
+}
+
+extern "C" int rlh_dense_apply_r1(int dtype, int64_t M, int64_t N, const void *A, int64_t lda, int order, int transp,
+                                  int64_t m, const void *X, int64_t ldx, void *Y, int64_t ldy, const void *d_u,
+                                  const void *d_c) {
   if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(d_c || !d_u, "rlh_dense_apply_r1: a vector u without coefficients c");
   RLH_REQUIRE(dtype_valid(dtype), "rlh_dense_apply: unknown dtype %d", dtype);
   RLH_REQUIRE(M >= 0 && N >= 0 && m >= 0, "rlh_dense_apply: negative size");
   RLH_REQUIRE(order == 0 || order == 1, "rlh_dense_apply: order must be 0 (row-major) or 1 (column-major)");
@@ -343,6 +623,7 @@ extern "C" int rlh_dense_apply(int dtype, int64_t M, int64_t N, const void *A, i
   a.a_kcontig = ((order == 0) != (transp == 1)) ? 1 : 0;
   a.conj_a = (transp == 1 && (dtype == RLH_C || dtype == RLH_Z)) ? 1 : 0;
   a.ny = ny; a.nx = nx; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.m = (int)m;
+  a.r1_u = d_u; a.r1_c = d_c;
   switch (dtype) {
     case RLH_S: return dense_impl<RLH_S>(a);
     case RLH_D: return dense_impl<RLH_D>(a);

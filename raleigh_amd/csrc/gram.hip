@@ -68,8 +68,16 @@ struct GramArgs {
 //         chunks in flight in two register sets (the compiler emits counted vmcnt waits only for
 //         straight-line load groups: with a predicate per load it waits for vmcnt(0)).
 // MULTI: the windows are concatenations of up to kGramSegs blocks (general loop, MODE 0, only).
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false>
-__global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) void gram_kernel(GramArgs a) {
+// QUAD (general loop, MODE 0, aligned, PI = 4, PJ = 2, 512 threads): the workgroup's panel is 128 x 128
+// real columns -- a complex128 block of 64 vectors against another -- and each of the EIGHT waves owns
+// a 64 x 32 part of it (4 x 2 tiles, 64 accumulator registers) over ALL rows of a chunk instead of the
+// whole panel over a quarter of the rows.  Wide
+// windows otherwise take several 64 x 64 panels, every one of which re-reads its column ranges of both
+// operands: at m = k = 64 complex128 that is twice the bytes, and the MFMA pipes idle while the one
+// resident workgroup per CU stages (measured 2.08 ms = 40 % of the fp64 MFMA rate, 25 % of the HBM rate;
+// the two bounds are 0.83 and 0.82 ms).  Chunks are 256-byte column pieces so that two workgroups fit a CU.
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false>
+__global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1)) void gram_kernel(GramArgs a) {
   using T = typename DType<DT>::T;
   using R = typename DType<DT>::R;
   using M = Mfma16<R>;
@@ -77,14 +85,19 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
   constexpr bool CPLX = DType<DT>::cplx;
   constexpr int NC = CPLX ? 2 : 1;               // reals per element
   constexpr int RM = MODE == 3 ? 2 : (MODE == 4 ? 4 : 1);
-  constexpr int ROWS = RM * 512 / (int)sizeof(R);   // rows per chunk: 512-byte column pieces, 1 KiB (MODE 3), 2 KiB (MODE 4)
+  // rows per chunk: 512-byte column pieces, 1 KiB (MODE 3), 2 KiB (MODE 4); QUAD: 256 bytes for the
+  // 128 x 128 panel, 512 bytes for the 64 x 64 one (two workgroups per CU either way)
+  constexpr int ROWS = QUAD ? (PI * PJ >= 8 ? 256 : 512) / (int)sizeof(R) : RM * 512 / (int)sizeof(R);
   constexpr int RPU = 16 / (int)sizeof(R);       // reals per 16-byte unit
   constexpr int UPC = ROWS * NC / RPU;           // units per T-column per chunk
-  constexpr int VY = PI * 16, VX = PJ * 16;      // real (virtual) columns per panel
+  constexpr int NT = QUAD ? 512 : 256;           // threads
+  constexpr int WQI = QUAD ? 2 : 1, WQJ = QUAD ? 4 : 1;   // waves per panel side
+  constexpr int VY = PI * 16 * WQI, VX = PJ * 16 * WQJ;   // real (virtual) columns per panel
+  static_assert(!QUAD || (MODE == 0 && ((PI == 4 && PJ == 2) || (PI == 2 && PJ == 1))), "quadrant panels are 128 x 128 or 64 x 64");
   constexpr int CY = VY / NC, CX = VX / NC;      // T columns per panel
   constexpr int S = ROWS + 2;                    // LDS column stride in reals (== 2 mod 32)
   constexpr int UNITS_MAX = (CY + CX) * UPC;
-  constexpr int UPT = (UNITS_MAX + 255) / 256;   // units per thread
+  constexpr int UPT = (UNITS_MAX + NT - 1) / NT; // units per thread
 
   __shared__ __attribute__((aligned(16))) R lds[(VY + VX) * S];
 
@@ -109,9 +122,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
   // the first UY pieces belong to the Y panel (none when the panel is shared with X), the rest to
   // the X panel.  Columns past the window are clamped to a valid one: they only feed Gram
   // entries that are never written out, so no zero fill is needed.
-  constexpr int CPQ = 256 / UPC;                 // columns covered by one pass of the 256 threads
+  constexpr int CPQ = NT / UPC;                  // columns covered by one pass of the threads
   constexpr int UYQ = CY / CPQ, UXQ = CX / CPQ;  // passes over the Y / X panel
-  static_assert(256 % UPC == 0 && CY % CPQ == 0 && CX % CPQ == 0, "panel / thread mapping");
+  static_assert(NT % UPC == 0 && CY % CPQ == 0 && CX % CPQ == 0, "panel / thread mapping");
   const int tcol = tid / UPC, tk = tid % UPC;
   const int uy = same_panel ? 0 : UYQ;           // wave-uniform
 
@@ -215,23 +228,25 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
     for (int j = 0; j < PJ; ++j) acc[i][j] = acc_t{(R)0, (R)0, (R)0, (R)0};
 
   const int fr = lane & 15, fk = lane >> 4;
+  // first tile row / column of this wave in the panel (QUAD: its quadrant)
+  const int ti0 = QUAD ? (wave >> 2) * PI : 0, tj0 = QUAD ? (wave & 3) * PJ : 0;
   auto mfma_phase = [&]() {
-    const int rbase = wave * (ROWS / 4);
+    const int rbase = QUAD ? 0 : wave * (ROWS / 4);
 #pragma unroll 4
-    for (int ks = 0; ks < ROWS / 16; ++ks) {
+    for (int ks = 0; ks < (QUAD ? ROWS / 4 : ROWS / 16); ++ks) {
       const int row = rbase + ks * 4 + fk;
       R fa[PI], fb[PJ];
 #pragma unroll
-      for (int i = 0; i < PI; ++i) fa[i] = ldsY[(i * 16 + fr) * S + row];
+      for (int i = 0; i < PI; ++i) fa[i] = ldsY[((ti0 + i) * 16 + fr) * S + row];
 #pragma unroll
-      for (int j = 0; j < PJ; ++j) fb[j] = ldsX[(j * 16 + fr) * S + row];
+      for (int j = 0; j < PJ; ++j) fb[j] = ldsX[((tj0 + j) * 16 + fr) * S + row];
 #pragma unroll
       for (int i = 0; i < PI; ++i)
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
           // a panel of a self-Gram is symmetric: only the tiles on and above its diagonal are
           // computed, gram_finalize mirrors the rest
-          if (same_panel && i > j) continue;
+          if (same_panel && ti0 + i > tj0 + j) continue;
           acc[i][j] = M::run(fa[i], fb[j], acc[i][j]);
         }
     }
@@ -312,10 +327,24 @@ __global__ __launch_bounds__(256, (MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1) voi
     }
   }
 
+  if constexpr (QUAD) {
+    // every wave owns its quadrant: straight from the accumulators to the partials
+    R *outq = reinterpret_cast<R *>(a.partials) + (int64_t)panel * (VY * VX) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < PI; ++i)
+#pragma unroll
+      for (int j = 0; j < PJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ii = (ti0 + i) * 16 + M::out_row(lane, r), jj = (tj0 + j) * 16 + (lane & 15);
+          outq[(int64_t)(ii * VX + jj) * gridDim.x] = acc[i][j][r];
+        }
+    return;
+  }
   // ---- combine the four waves in a fixed order through LDS, then write the partial
   __syncthreads();
   constexpr int TILE = 256;   // reals per 16x16 tile
-  static_assert(PI * PJ * TILE <= (VY + VX) * S, "epilogue does not fit the staging tile");
+  static_assert(QUAD || PI * PJ * TILE <= (VY + VX) * S, "epilogue does not fit the staging tile");
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -381,12 +410,12 @@ __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int 
 }
 
 // Resident workgroups per CU for one instantiation (registers + LDS), asked once.
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false>
 static int gram_blocks_per_cu() {
   static int cached = 0;
   if (cached == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI>, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD>, QUAD ? 512 : 256, 0) != hipSuccess ||
         nb < 1)
       nb = 1;
     cached = nb > 8 ? 8 : nb;
@@ -396,28 +425,33 @@ static int gram_blocks_per_cu() {
   return cached;
 }
 
+static inline bool env_quad() {         // RLH_GRAM_QUAD=0: no quadrant panels (tunable)
+  const char *e = getenv("RLH_GRAM_QUAD");
+  return !(e && *e == '0');
+}
+
 static inline int pick_tiles(int v) {   // 16x16 tiles per panel side: 1, 2 or 4
   if (v <= 16) return 1;
   if (v <= 32) return 2;
   return 4;
 }
 
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false>
 static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, void *d_out) {
   using R = typename DType<DT>::R;
   Context &c = ctx();
-  constexpr int VY = PI * 16, VX = PJ * 16;
+  constexpr int VY = PI * 16 * (QUAD ? 2 : 1), VX = PJ * 16 * (QUAD ? 4 : 1);
   const int npanels = npi * npj;
   // the grid is sized to what is resident at once: every workgroup strides over the row
   // chunks, so a second, partially filled round of workgroups would only add a tail
-  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE, MULTI>() / npanels;
+  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD>() / npanels;
   if (nbx < 1) nbx = 1;
   if (nbx > a.nchunks) nbx = a.nchunks;
   const size_t part_bytes = sizeof(R) * VY * VX;
   while (nbx > 1 && (size_t)nbx * npanels * part_bytes > kWorkspaceBytes) nbx /= 2;
   RLH_REQUIRE((size_t)nbx * npanels * part_bytes <= kWorkspaceBytes,
               "rlh_gram: %lld x %lld result exceeds the reduction workspace", (long long)my, (long long)mx);
-  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI>), dim3((unsigned)nbx, (unsigned)npanels), dim3(256), 0,
+  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD>), dim3((unsigned)nbx, (unsigned)npanels), dim3(QUAD ? 512 : 256), 0,
                      c.stream, a);
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
@@ -455,6 +489,18 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
     if (a.same && npi == 1 && npj == 1 && PI == PJ && PI <= 2) mode = 2;   // (longer chunks instead: 0.48 -> 0.535 ms)
     else if (!a.same && pipe >= 2 && PI * PJ <= 4) mode = 1;
     else if (PI <= 2 && PJ <= 2 && rows_cap >= 2) mode = (PI * PJ == 1 && rows_cap >= 4) ? 4 : 3;
+  }
+  // windows of more than 64 real columns: 128 x 128 panels with one quadrant per wave (see gram_kernel)
+  if (aligned && (vx > 64 || vy > 64) && vx > 32 && vy > 32 && env_quad()) {
+    a.npj = (vx + 127) / 128;
+    a.nchunks = (n + 256 / (int)sizeof(R) - 1) / (256 / (int)sizeof(R));
+    return gram_launch<DT, 4, 2, true, 0, false, true>(a, (vy + 127) / 128, a.npj, my, mx, d_out);
+  }
+  // 33 .. 64 real columns on both sides: one 64 x 64 panel, 2 x 1 tiles per wave of a 512-thread workgroup
+  if (aligned && vx > 32 && vy > 32 && vx <= 64 && vy <= 64 && env_quad()) {
+    a.npj = 1;
+    a.nchunks = (n + 512 / (int)sizeof(R) - 1) / (512 / (int)sizeof(R));
+    return gram_launch<DT, 2, 1, true, 0, false, true>(a, 1, 1, my, mx, d_out);
   }
   const int ROWS = (mode == 3 ? 2 : (mode == 4 ? 4 : 1)) * 512 / (int)sizeof(R);
   a.nchunks = (n + ROWS - 1) / ROWS;

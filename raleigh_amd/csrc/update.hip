@@ -195,11 +195,160 @@ static int launch_update_rv(const T *X, int64_t ldx, T *Out, int64_t ldo, const 
   return 0;
 }
 
+// ---------------------------------------------------------------- complex block update on the matrix cores
+// Out = beta Out + X Q for the complex types with k, m >= 16: 8 n k m real flops on 32 n m bytes (complex128,
+// k = m = 64: 16 flop/byte), i.e. bound by arithmetic, and the SGPR-fed VALU kernel above reaches 42 % of the
+// fp64 rate there (2.0 ms at n = 2 x 10^6).  Here the product runs as four real MFMA products
+//   Out_r = X_r Q_r - X_i Q_i,   Out_i = X_r Q_i + X_i Q_r
+// on v_mfma_{f64,f32}_16x16x4 with the ROWS of X on the lanes: D^T (16 output columns x 16 rows) =
+// Q^T (16 x 4) X^T (4 x 16), so a lane holds (re, im) of one row and 4 output columns and stores them as
+// 16-byte pieces, 16 lanes = 256 contiguous bytes of a column of Out.
+//  * X: each lane loads ITS 16-byte element (row lane & 15, column 4 s + (lane >> 4)) of every k-step
+//    straight from global memory (256-byte runs), one row tile ahead of the arithmetic; no LDS staging;
+//  * Q: re-laid-out once per workgroup into the LDS in fragment order [column tile][k-step][lane] = (re, im) of
+//    Q[4 s + (lane >> 4), 16 t + (lane & 15)], one ds_read_b128 per k-step and column tile;
+//  * a wave takes 16 rows and walks all column tiles with the X fragments in registers: X is read once,
+//    Out written (and for beta = 1 read) once.
+template <typename R> struct Mfma16x4;
+template <> struct Mfma16x4<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma16x4<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+
+constexpr int kMfmaUpdKS = 32;               // k-steps (of 4 columns) whose X fragments a wave keeps in registers
+
+template <typename T, typename R, bool BETA>
+__global__ __launch_bounds__(256) void block_update_mfma_kernel(const T *__restrict__ X, int64_t ldx, int k1, int ks1,
+                                                                const T *__restrict__ X2, int64_t ldx2, int k2, int ks2,
+                                                                T *__restrict__ Out, int64_t ldo, T *__restrict__ Out2,
+                                                                int64_t ldo2, int msplit, const T *__restrict__ Q, int ldq,
+                                                                int64_t n, int m) {
+  using M = Mfma16x4<R>;
+  using acc_t = typename M::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  T *qf = reinterpret_cast<T *>(lds_raw);                 // [column tile][k-step][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nks = ks1 + ks2, ntile = (m + 15) / 16;
+  for (int idx = tid; idx < ntile * nks * 64; idx += 256) {
+    const int l = idx & 63, s = (idx >> 6) % nks, t = (idx >> 6) / nks;
+    const int col = 16 * t + (l & 15);
+    T q = zero_of(T{});
+    if (col < m) q = Q[(int64_t)(4 * s + (l >> 4)) * ldq + col];   // (rows past k1 / k2 inside their padded parts are zero)
+    qf[idx] = q;
+  }
+  __syncthreads();
+  const int64_t ntiles_rows = (n + 15) / 16;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int kk = lane >> 4, rl = lane & 15;
+  T xf[kMfmaUpdKS];
+  auto load_x = [&](int64_t rt) {
+    int64_t r = rt * 16 + rl;
+    r = r < n ? r : n - 1;                                 // rows past the end repeat the last (never stored)
+#pragma unroll
+    for (int s = 0; s < kMfmaUpdKS; ++s) {
+      if (s < nks) {                                       // (workgroup-uniform)
+        const bool first = s < ks1;
+        int c = first ? 4 * s + kk : 4 * (s - ks1) + kk;
+        const int kmax = first ? k1 : k2;
+        c = c < kmax ? c : kmax - 1;                       // columns inside the zero padding of Q
+        xf[s] = first ? X[r + (int64_t)c * ldx] : X2[r + (int64_t)c * ldx2];
+      }
+    }
+  };
+  for (int64_t rt = wave_id; rt < ntiles_rows; rt += nwaves) {
+    load_x(rt);
+    const int64_t row = rt * 16 + rl;
+    for (int t = 0; t < ntile; ++t) {
+      acc_t dr = {(R)0, (R)0, (R)0, (R)0}, di = {(R)0, (R)0, (R)0, (R)0};
+      if (BETA) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = 16 * t + M::out_row(lane, g);
+          if (j < m && row < n) {
+            const T o = j < msplit ? Out[row + (int64_t)j * ldo] : Out2[row + (int64_t)(j - msplit) * ldo2];
+            dr[g] = o.re; di[g] = o.im;
+          }
+        }
+      }
+      const T *qt = qf + (int64_t)t * nks * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < kMfmaUpdKS; ++s) {
+        if (s < nks) {
+          const T q = qt[s * 64];
+          const T x = xf[s];
+          dr = M::run(q.re, x.re, dr);
+          dr = M::run(q.im, -x.im, dr);
+          di = M::run(q.im, x.re, di);
+          di = M::run(q.re, x.im, di);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = 16 * t + M::out_row(lane, g);
+        if (j < m && row < n) {
+          T *o = j < msplit ? Out + row + (int64_t)j * ldo : Out2 + row + (int64_t)(j - msplit) * ldo2;
+          *o = T{dr[g], di[g]};
+        }
+      }
+    }
+  }
+}
+
+// The matrix-core path: complex types, every k-step in registers, Q in the LDS.
+template <typename T>
+static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
+                              int beta, const T *X2, int64_t ldx2, int k2, int kpad, T *Out2, int64_t ldo2, int msplit) {
+  using R = decltype(T{}.re);
+  Context &c = ctx();
+  const int ks1 = X2 && k2 > 0 ? kpad / 4 : (k + 3) / 4, ks2 = X2 && k2 > 0 ? (k2 + 3) / 4 : 0;
+  const int ntile = (m + 15) / 16;
+  const size_t lds = (size_t)ntile * (ks1 + ks2) * 64 * sizeof(T);
+  static bool attr = false;
+  if (!attr) {
+    RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_update_mfma_kernel<T, R, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_update_mfma_kernel<T, R, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  int64_t nb = (int64_t)c.num_cu * (lds <= 80 * 1024 ? 2 : 1);
+  const int64_t need = ((n + 15) / 16 + 3) / 4;
+  if (nb > need) nb = need;
+  if (nb < 1) nb = 1;
+  if (beta)
+    hipLaunchKernelGGL((block_update_mfma_kernel<T, R, true>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, k, ks1, X2, ldx2,
+                       k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m);
+  else
+    hipLaunchKernelGGL((block_update_mfma_kernel<T, R, false>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, k, ks1, X2, ldx2,
+                       k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T> struct IsComplex { static constexpr bool value = false; };
+template <> struct IsComplex<c32> { static constexpr bool value = true; };
+template <> struct IsComplex<c64> { static constexpr bool value = true; };
+
 template <typename T, int JT>
 static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
                          int beta, const T *X2 = nullptr, int64_t ldx2 = 0, int k2 = 0, int kpad = 0,
                          T *Out2 = nullptr, int64_t ldo2 = 0, int msplit = -1) {
   if (msplit < 0 || !Out2) { msplit = m; Out2 = Out; ldo2 = ldo; }
+  if constexpr (IsComplex<T>::value) {
+    // the matrix cores for complex blocks of at least 16 x 16 coefficients whose k-steps fit the register
+    // set and whose coefficients fit the LDS (RLH_UPDATE_MFMA=0: VALU kernel, tunable)
+    const int ks = (X2 && k2 > 0 ? kpad / 4 + (k2 + 3) / 4 : (k + 3) / 4);
+    const size_t lds = (size_t)((m + 15) / 16) * ks * 64 * sizeof(T);
+    if (env_flag("RLH_UPDATE_MFMA", 1) && k + k2 >= 16 && m >= 16 && ks <= kMfmaUpdKS && lds <= 160 * 1024 &&
+        aligned16(X, ldx, sizeof(T)) && (!X2 || k2 == 0 || aligned16(X2, ldx2, sizeof(T))))
+      return launch_update_mfma<T>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad, Out2, ldo2, msplit);
+  }
   // 16-byte row groups where RV * JT accumulators of T fit (<= 128 registers) and every block is
   // 16-byte aligned (RLH_UPDATE_RV=0: one row per lane, tunable)
   constexpr int RVMAX = 16 / (int)sizeof(T);

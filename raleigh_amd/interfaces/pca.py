@@ -23,8 +23,20 @@ from ..core.solver import Problem, Solver, Options
 
 
 class _OperatorSVD:
-    """x -> A_s^T A_s x (or A_s A_s^T x when there are fewer samples than features), A_s = A - e a
-    the mean-shifted data (partial_svd.py:238-301)."""
+    """The normal operator of the mean-shifted data A_s = A - e a^T (e: ones over the M samples, a: the
+    N column means) for the block eigensolver: x -> A_s^T (A_s x) when M >= N, x -> A_s (A_s^T x)
+    otherwise (the role of raleigh/interfaces/partial_svd.py:238-301).
+
+    Written from the algebra.  With c = a^T x (k numbers per block):
+        M >= N:   z = A x - e c^T        (centred: e^T z = 0 up to rounding, so A_s^T z = A^T z)
+                  y = A^T z
+        M <  N:   z = A^T x - a s^T,  s = e^T x
+                  y = A z - e t^T,    t = a^T z
+    On a Matrix with `apply_r1` every rank-one term rides in the epilogue of its GEMM
+    (rlh_dense_apply_r1) and the coefficient vectors are formed on the device by a one-column Gram, so
+    an application is two GEMMs and one or two small reductions, with no host synchronisation and no
+    extra pass over the M x k or N x k block (the reference makes two dot + add passes per product).
+    Other operators (row-sharded data) take the same steps with dot / add calls."""
 
     def __init__(self, matrix, v, transp=False, shift=False):
         self.op = matrix.as_operator()
@@ -36,38 +48,61 @@ class _OperatorSVD:
         # vectors are created by the OPERATOR so that a row-sharded matrix can hand out
         # sharded vectors for its row dimension and replicated ones for its column dimension
         self.w = self.op.new_vectors(n if transp else m, 0)
+        self._fused = hasattr(self.op, 'apply_r1')
+        self._coef = None
         if shift:
             dt = self.op.data_type()
-            ones = numpy.ones((1, m), dtype=dt)
             self.ones = self.op.new_vectors(m, 1)
-            self.ones.fill(ones)
+            self.ones.fill(numpy.ones((1, m), dtype=dt))
             self.aves = self.op.new_vectors(n, 1)
-            self.op.apply(self.ones, self.aves, transp=True)
-            self.aves.scale(m * ones[0, :1])          # column means a
+            self.op.apply(self.ones, self.aves, transp=True)     # A^H e = M conj(a)
+            self.aves.scale(numpy.full((1,), m, dtype=dt))
+            if self.aves.is_complex():
+                self.aves.conjugate()                            # a itself
+            # <x, conj(a)> = a^T x: the one-column Gram conjugates its second argument
+            self.aves_c = self.aves
+            if self.aves.is_complex():
+                self.aves_c = self.aves.clone()
+                self.aves_c.conjugate()
+
+    def _coefficients(self, k, slot):
+        from ..algebra.hip.memory import DeviceBuffer
+        es = numpy.dtype(self.op.data_type()).itemsize
+        if self._coef is None or self._coef.nbytes < 2 * k * es:
+            self._coef = DeviceBuffer(2 * max(k, 16) * es, zero=False)
+        return self._coef.ptr + slot * k * es
 
     def apply(self, x, y):
         m, n = self.op.shape()
         k = x.nvec()
         start = time.time()
-        if self.transp:
-            if self.w.nvec() < k:
-                self.w = self.op.new_vectors(n, k)
-            z = self.w
-            z.select(k)
+        if self.w.nvec() < k or self.w.shape()[0] < k:
+            self.w = self.op.new_vectors(n if self.transp else m, k)
+        z = self.w
+        z.select(k)
+        if not self.shift:
+            self.op.apply(x, z, transp=self.transp)
+            self.op.apply(z, y, transp=not self.transp)
+        elif self._fused:
+            from ..algebra.hip.matrix import coefficients_into
+            c0, c1 = self._coefficients(k, 0), self._coefficients(k, 1)
+            if self.transp:
+                coefficients_into(c0, x, self.ones)                       # s = e^T x
+                self.op.apply_r1(x, z, True, self.aves, c0)               # z = A^T x - a s^T
+                coefficients_into(c1, z, self.aves_c)                     # t = a^T z
+                self.op.apply_r1(z, y, False, None, c1)                   # y = A z - e t^T
+            else:
+                coefficients_into(c0, x, self.aves_c)                     # c = a^T x
+                self.op.apply_r1(x, z, False, None, c0)                   # z = A x - e c^T
+                self.op.apply(z, y, transp=True)                          # y = A^T z
+        elif self.transp:
             self.op.apply(x, z, transp=True)
-            if self.shift:
-                z.add(self.aves, -1, x.dot(self.ones))
+            z.add(self.aves, -1.0, x.dot(self.ones))                      # - a (e^T x)
             self.op.apply(z, y)
-            if self.shift:
-                y.add(self.ones, -1, z.dot(self.aves))
+            y.add(self.ones, -1.0, z.dot(self.aves_c))                    # - e (a^T z)
         else:
-            if self.w.nvec() < k:
-                self.w = self.op.new_vectors(m, k)
-            z = self.w
-            z.select(k)
             self.op.apply(x, z)
-            if self.shift:      # remove the mean along e, twice for accuracy
-                z.add(self.ones, -1.0 / m, z.dot(self.ones))
+            for _ in range(2):          # the mean of every column of z along e, removed twice for accuracy
                 z.add(self.ones, -1.0 / m, z.dot(self.ones))
             self.op.apply(z, y, transp=True)
         if self.gpu is not None:

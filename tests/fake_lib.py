@@ -522,6 +522,9 @@ class FakeLib:
         return 0
 
     def rlh_dense_apply(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy):
+        return self.rlh_dense_apply_r1(code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy, None, None)
+
+    def rlh_dense_apply_r1(self, code, M, N, A, lda, order, transp, m, X, ldx, Y, ldy, d_u, d_c):
         self._count('dense_apply')
         if order == 0:
             a = _block(A, code, N, M, lda)              # rows of A, shape (M, N)
@@ -531,7 +534,12 @@ class FakeLib:
         if ldx < nx or ldy < ny:
             return self._fail('rlh_dense_apply: Matrix and vectors dimensions incompatible')
         x = _block(X, code, nx, m, ldx)
-        _block(Y, code, ny, m, ldy)[:, :] = ops.dense_apply(a, x, bool(transp))
+        y = ops.dense_apply(a, x, bool(transp))
+        if _addr(d_c):
+            c = _flat(d_c, _DT[code], m)
+            u = _flat(d_u, _DT[code], ny) if _addr(d_u) else np.ones(ny, dtype=_DT[code])
+            y = y - c[:, None] * u[None, :]
+        _block(Y, code, ny, m, ldy)[:, :] = y
         return 0
 
     def rlh_timer_start(self):

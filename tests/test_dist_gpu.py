@@ -1,0 +1,103 @@
+"""The row-sharded (torch.distributed / RCCL) code path on ONE GPU with the collectives forced: the
+all-reduce of every reduction, the halo exchange of the sparse operator (pack -> send to self -> receive
+-> halo block -> boundary rows) and their ordering with the kernels' stream run on hardware, which a
+single rank otherwise skips ("no RCCL collective has ever executed")."""
+
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ops
+from oracle.sparse import lap3d
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def comm():
+    import torch
+    import torch.distributed as dist
+    from raleigh_amd import _lib
+    _lib.set_library(None)
+    L = _lib.lib()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29561')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    from raleigh_amd.algebra.hip.dist import Comm
+    c = Comm(force_collectives=True)
+    yield c
+    _lib.check(L.rlh_sync())
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    _lib.check(L.rlh_set_stream(None))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.complex128, np.float32])
+def test_reductions_through_rccl(comm, dt):
+    from raleigh_amd.algebra.hip.dist import ShardedVectors
+    rng = np.random.default_rng(5)
+    n, m, k = 50021, 12, 7
+    x = rng.standard_normal((m, n)).astype(dt)
+    y = rng.standard_normal((k, n)).astype(dt)
+    if dt == np.complex128:
+        x = x + 1j * rng.standard_normal((m, n))
+        y = y - 1j * rng.standard_normal((k, n))
+    tol = 2e-5 if dt == np.float32 else 1e-13
+    X, Y = ShardedVectors(x, comm=comm), ShardedVectors(y, comm=comm)
+    assert rel(X.dot(Y), ops.gram(x, y)) < tol
+    assert rel(X.dots(X), ops.dots(x, x)) < tol
+    rb = X.reduction_batch()
+    rb.gram([X], [Y, X])
+    rb.dots(Y, Y)
+    g, d = rb.run()
+    assert rel(g[:k], ops.gram(x, y)) < tol and rel(g[k:], ops.gram(x, x)) < tol and rel(d, ops.dots(y, y)) < tol
+    assert np.array_equal(X.data(), x)                    # all-gather of the shards
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_halo_exchange_with_itself(comm, dt):
+    """Half of the own rows is fetched through the halo path (RLH_FORCE_COLLECTIVES semantics of
+    ShardedSparseMatrix with one rank): gather_rows, batch_isend_irecv to the own rank, the strided
+    copy into the halo block and the interior / boundary split of the windowed kernel."""
+    from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix
+    A = lap3d(40, 40, 40, 1.0, 1.01, 1.02).astype(dt)
+    n = A.shape[0]
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((9, n)).astype(dt)
+    op = ShardedSparseMatrix(A, comm)
+    assert op.halo_rows() > n // 3                        # the forced self-exchange is really there
+    X, Y = ShardedVectors(x, comm=comm), ShardedVectors(n, 9, dt, comm=comm)
+    op.apply(X, Y)
+    ref = ops.csr_sym_apply(sp.triu(A, format='csr'), x)
+    assert rel(Y.data(), ref) < (3e-6 if dt == np.float32 else 1e-13)
+    # the fused Chebyshev step through the same exchange
+    p0, b0 = rng.standard_normal((9, n)).astype(dt), rng.standard_normal((9, n)).astype(dt)
+    P, B = ShardedVectors(p0.copy(), comm=comm), ShardedVectors(b0.copy(), comm=comm)
+    op.cheb_step(X, P, B, 1.25, -0.25, 0.5)
+    assert rel(P.data(), 1.25 * x - 0.25 * p0 + 0.5 * (b0 - ref)) < (5e-6 if dt == np.float32 else 1e-13)
+
+
+def test_sharded_driver_with_forced_collectives(comm):
+    """The block-JCG driver on row-sharded vectors: every batch of reductions goes through one all-reduce."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix
+    from raleigh_amd.algebra.hip.precond import ChebyshevPreconditioner, gershgorin_upper_bound
+    from oracle.sparse import lap3d_eigenvalues
+    A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    op = ShardedSparseMatrix(A, comm)
+    T = ChebyshevPreconditioner(op, gershgorin_upper_bound(A), ratio=300.0, degree=10)
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(None, T=T, which=6, tol=1e-6, verb=-1, operator=op,
+                                  vectors=lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm))
+    assert status == 0
+    assert np.allclose(lmd[:6], lap3d_eigenvalues(30, 30, 30, 1.0, 1.01, 1.02, 6), rtol=1e-10)

@@ -55,9 +55,10 @@ def test_sparse_golden(golden_dir):
 
 @pytest.mark.parametrize('key', KEYS)
 @pytest.mark.parametrize('n,mx,my', [(1, 1, 1), (63, 3, 2), (1000, 8, 8), (4097, 16, 5), (20011, 32, 32),
-                                     (20000, 33, 7), (9999, 70, 40), (5000, 130, 3)])
+                                     (20000, 33, 7), (9999, 70, 40), (5000, 130, 3), (7777, 64, 64), (3001, 100, 129)])
 def test_gram_vs_oracle(key, n, mx, my):
-    """Panels of 1/2/4 tiles, ragged tails, odd n (unaligned columns when ld is not padded)."""
+    """Panels of 1/2/4 tiles, 128 x 128 panels with one part per wave (windows of more than 64 real
+    columns), ragged tails, odd n (unaligned columns when ld is not padded)."""
     from raleigh_amd.algebra.hip import Vectors
     rng = np.random.default_rng(n + mx)
     x, y = rnd((mx, n), key, rng), rnd((my, n), key, rng)
@@ -886,3 +887,35 @@ def test_config3_surrogate_apply_full_size():
     X, Y = Vectors(x), Vectors(n, 16)
     op.apply(X, Y)
     assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < 1e-13
+
+
+@pytest.mark.parametrize('key', KEYS)
+@pytest.mark.parametrize('M,N,m,transp', [(300, 200, 7, False), (1000, 513, 33, True), (4000, 2500, 128, False),
+                                           (2500, 6000, 70, True)])
+def test_dense_apply_with_rank_one_epilogue(key, M, N, m, transp):
+    """rlh_dense_apply_r1: Y = Op(A) X - u c^T with the rank-one term folded into the tile store (no K
+    split) or into the split-K reduction (the 4000 x 2500 and 2500 x 6000 cases split K), u given or a
+    vector of ones, coefficients produced on the device by a one-column Gram -- the mean shift of the
+    PCA operator (raleigh/interfaces/partial_svd.py:258-291)."""
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    from raleigh_amd.algebra.hip.matrix import coefficients_into
+    from raleigh_amd.algebra.hip.memory import DeviceBuffer
+    rng = np.random.default_rng(M + m)
+    a = rnd((M, N), key, rng)
+    nx, ny = (M, N) if transp else (N, M)
+    x = rnd((m, nx), key, rng)
+    w = rnd((1, nx), key, rng)
+    u = rnd((1, ny), key, rng)
+    A, X, W, U = Matrix(a), Vectors(x), Vectors(w), Vectors(u)
+    Y = Vectors(ny, m, data_type=DT[key])
+    cbuf = DeviceBuffer(m * np.dtype(DT[key]).itemsize, zero=False)
+    coefficients_into(cbuf.ptr, X, W)                      # c[j] = w^H x_j, left on the device
+    c = (x.astype(np.complex128) @ np.conj(w[0].astype(np.complex128)))
+    ref0 = (a.conj().T if transp else a).astype(np.complex128) @ x.T.astype(np.complex128)
+    tol = 3e-5 if key in 'sc' else 1e-12
+    for uvec, uref in ((U, u[0].astype(np.complex128)), (None, np.ones(ny))):
+        A.apply_r1(X, Y, transp, uvec, cbuf.ptr)
+        ref = (ref0 - np.outer(uref, c)).T
+        assert cases.rel(Y.data(), ref if key in 'cz' else ref.real) < tol
+    A.apply(X, Y, transp)
+    assert cases.rel(Y.data(), ref0.T if key in 'cz' else ref0.T.real) < tol

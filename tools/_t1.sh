@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for ct in 0 512 2048; do for sl in 2 8; do echo "chain_tasks=$ct sl=$sl"; RLH_SPTRSV_CHAIN_TASKS=$ct RLH_SPTRSV_SLICES=$sl timeout -k 10 300 python tools/ilu_bench.py fe 2>&1 | grep "apply m"; done; done
-for ct in 0 512 4096; do echo "lap30 chain_tasks=$ct"; RLH_SPTRSV_CHAIN_TASKS=$ct timeout -k 10 300 python tools/ilu_bench.py lap30 2>&1 | grep "apply m"; done
-for ct in 0 4096 65536; do echo "lap100 chain_tasks=$ct"; RLH_SPTRSV_CHAIN_TASKS=$ct timeout -k 10 300 python tools/ilu_bench.py lap100 2>&1 | grep "apply m"; done
-timeout -k 10 900 python -m pytest tests/test_configs_gpu.py tests/test_driver_gpu.py -x -q -m gpu > gpurun_out/t_cfg3.log 2>&1; echo rc=$?; tail -4 gpurun_out/t_cfg3.log
+for dbg in 0 8; do for sch in 1 0; do echo "== fe debug=$dbg sched=$sch"; RLH_SPMM_SCHED=$sch RLH_WIDE_DEBUG=$dbg timeout -k 10 100 python tools/microbench.py --fe --m 16 --only spmm 2>&1 | grep "per application"; done; done
+echo "== band15 nt"; RLH_WIDE_DEBUG=8 timeout -k 10 200 python tools/microbench.py --n 9938375 --m 32 --band 15 --only spmm 2>&1 | grep "spmm band"
+echo "== band15"; timeout -k 10 200 python tools/microbench.py --n 9938375 --m 32 --band 15 --only spmm 2>&1 | grep "spmm band"
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/t_all1.log 2>&1; echo rc=$?; tail -5 gpurun_out/t_all1.log
