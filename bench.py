@@ -426,14 +426,24 @@ def main():
 
     from raleigh_amd import _lib
     from raleigh_amd.algebra.hip import Vectors
+    # rehearsal of the multi-rank control flow on a machine without GPUs (tests/test_bench_rehearsal.py): the
+    # C-ABI stand-in of the test tier on host memory and the gloo backend; never set on a GPU box
+    rehearsal = os.environ.get('RLH_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import fake_lib
+        fake_lib.install()
     comm = None
     if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, partition
         comm = Comm(force_collectives=True if args.force_dist else None)
     L = _lib.lib(local_rank)
@@ -443,15 +453,17 @@ def main():
         _lib.check(L.rlh_sync())
         if comm is not None:
             import torch
-            torch.cuda.synchronize()
+            if not rehearsal:
+                torch.cuda.synchronize()
             comm.barrier()
-            torch.cuda.synchronize()
+            if not rehearsal:
+                torch.cuda.synchronize()
 
     def max_over_ranks(x):
         if comm is None:
             return x
         import torch
-        t = torch.tensor([x], dtype=torch.float64, device='cuda')
+        t = torch.tensor([x], dtype=torch.float64, device=comm.device)
         comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -550,7 +562,7 @@ def main():
         also = {'scaling': other, 'value': round(r2['value'], 1), 'unit': 'GB/s', 'ms_per_step': round(r2['ms_per_step'], 4),
                 'n': r2['n'], 'rows_per_gpu': r2['nloc']}
 
-    achieved = main_res['gram_bytes'] / (main_res['gram_ms'] * 1e-3) / 1e9
+    achieved = main_res['gram_bytes'] / (max(main_res['gram_ms'], 1e-9) * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'gram_traffic.json')
     if os.path.exists(tpath) and world == 1:

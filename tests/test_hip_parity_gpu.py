@@ -919,3 +919,41 @@ def test_dense_apply_with_rank_one_epilogue(key, M, N, m, transp):
         assert cases.rel(Y.data(), ref if key in 'cz' else ref.real) < tol
     A.apply(X, Y, transp)
     assert cases.rel(Y.data(), ref0.T if key in 'cz' else ref0.T.real) < tol
+
+
+@pytest.mark.parametrize('key', ['c', 'z'])
+@pytest.mark.parametrize('n,k,m', [(100003, 64, 64), (20000, 16, 16), (5001, 33, 70), (777, 128, 17)])
+def test_complex_block_update_on_matrix_cores(monkeypatch, key, n, k, m):
+    """The MFMA path of the complex block update (k, m >= 16): multiply, add with a scalar factor, the
+    two-source and the two-source / two-output forms, against the oracle and against the VALU kernel
+    (RLH_UPDATE_MFMA=0), ragged row tails and coefficient shapes that are not multiples of the tiles."""
+    from raleigh_amd.algebra.hip import Vectors
+    rng = np.random.default_rng(n + k + m)
+    x, x2 = rnd((k, n), key, rng), rnd((k + 3, n), key, rng)
+    q, q2 = rnd((k, m), key, rng), rnd((k + 3, m), key, rng)
+    w0 = rnd((m, n), key, rng)
+    tol = 3e-5 if key == 'c' else 1e-12
+    big = np.complex128
+    ref_mul = (x.T.astype(big) @ q.astype(big)).T
+    ref_add = w0.astype(big) + (0.5 - 0.25j) * ref_mul
+    ref_two = ref_mul + (x2.T.astype(big) @ q2.astype(big)).T
+    out = {}
+    for mfma in ('1', '0'):
+        monkeypatch.setenv('RLH_UPDATE_MFMA', mfma)
+        X, X2, W = Vectors(x), Vectors(x2), Vectors(n, m, data_type=DT[key])
+        X.multiply(q, W)
+        r_mul = W.data()
+        W.fill(w0)
+        W.add(X, 0.5 - 0.25j, q)
+        r_add = W.data()
+        X.combine(q, X2, q2, W)
+        r_two = W.data()
+        ma = m // 2
+        WA, WB = Vectors(n, ma, data_type=DT[key]), Vectors(n, m - ma, data_type=DT[key])
+        X.combine2(q[:, :ma], q[:, ma:], X2, q2[:, :ma], q2[:, ma:], WA, WB)
+        r_2x2 = np.concatenate((WA.data(), WB.data()))
+        out[mfma] = (r_mul, r_add, r_two, r_2x2)
+        for got, ref in ((r_mul, ref_mul), (r_add, ref_add), (r_two, ref_two), (r_2x2, ref_two)):
+            assert cases.rel(got, ref) < tol
+    for a, b in zip(out['1'], out['0']):
+        assert cases.rel(a, b) < tol

@@ -42,9 +42,9 @@ for k in sorted(acc['fetch']):
                                            'write_avg': sum(wr) / len(wr)}
 g = [k for k in acc['fetch'] if k.startswith('gram_kernel')]
 if g:
-    # the two-operand launches: the Gram kernel variant with the larger read volume per launch
-    # (the self-Gram runs under another template instance or, in older builds, the same one)
-    gk = max(g, key=lambda k: max(acc['fetch'][k]))
+    # the headline's two-operand X.dot(Y) launches: the Gram instance launched most often (the self-Gram and
+    # the stacked multi-block Grams of the fused leg run under other template instances)
+    gk = max(g, key=lambda k: len(acc['fetch'][k]))
     rd = sorted(2 * v * 1024 for v in acc['fetch'][gk])
     two = [v for v in rd if v > 0.75 * rd[-1]]
     wr = acc['write'][gk]
