@@ -54,6 +54,7 @@ struct GramArgs {
   int64_t nchunks;
   void *partials;     // [npanels][gridDim.x][VY][VX] reals
   int nxs, nys;       // segments of the X / Y window (MULTI kernels only)
+  int nt;             // non-temporal loads of the blocks (each byte is read once per launch)
   GramSeg xs[kGramSegs], ys[kGramSegs];
 };
 
@@ -161,13 +162,16 @@ __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2
     }
   };
 
+  // (plain loads: a run-time choice of the non-temporal hint would put every load behind a branch; the streaming
+  // kernel below, which serves the roofline shapes, takes the hint as a template parameter)
+  auto load_piece = [&](const R *p) -> vec_t { return *reinterpret_cast<const vec_t *>(p); };
   auto load_chunk = [&](int64_t chunk) {
     const int64_t row0 = chunk * ROWS;
     const bool full = ALIGNED && (row0 + ROWS <= a.n);          // wave-uniform
     if (full) {
 #pragma unroll
       for (int q = 0; q < UPT; ++q)
-        if (q < uy + UXQ) regs[q] = *reinterpret_cast<const vec_t *>(piece_ptr(q, row0));
+        if (q < uy + UXQ) regs[q] = load_piece(piece_ptr(q, row0));
     } else {                                                     // last chunk / unaligned layout
       const int64_t rend = (a.n - row0) * NC - (int64_t)tk * RPU;   // valid reals from this piece on
 #pragma unroll
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2
     auto load_full = [&](int64_t chunk, vec_t (&r)[UPT]) {
       const int64_t row0 = chunk * ROWS;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) r[q] = *reinterpret_cast<const vec_t *>(piece_ptr(q, row0));
+      for (int q = 0; q < NQ; ++q) r[q] = load_piece(piece_ptr(q, row0));
     };
     const int64_t nfull = a.n / ROWS;                     // chunks with all ROWS rows
     const int64_t G = gridDim.x;
@@ -461,6 +465,221 @@ static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, vo
   return 0;
 }
 
+// Blocks that cannot stay in the 256 MB Infinity Cache between two launches are read with the non-temporal
+// hint: measured on the access structure of this kernel (tools/stream_probe.hip) 6.1-6.2 -> 6.8-7.0 TB/s.
+// Smaller blocks keep the default policy, under which a following launch finds them cached (RLH_GRAM_NT forces).
+static int gram_nt(int64_t bytes) {
+  const char *e = getenv("RLH_GRAM_NT");
+  if (e && *e) return atoi(e);
+  return bytes > (int64_t)192 << 20;
+}
+
+// ---------------------------------------------------------------- wave-private streaming Gram
+// The roofline shapes -- real blocks, 16-byte aligned, at most 32 columns on the X side and 64 (two stacked blocks
+// of the solver's fused reductions) on the Y side -- without any workgroup barrier.
+// A workgroup is ONE wave.  It stages its own tile of TB bytes per column (32 fp64 rows at TB = 256) of the
+// Y and X columns through registers into its private LDS image, and multiplies the tile out of the image while
+// the loads of its next TWO tiles are in flight (two register sets): no wave ever waits for another one, and the
+// memory system always has work queued.  The 256-thread kernel above spends 12 % of its time around its two
+// barriers per chunk -- with the arithmetic AND the LDS traffic switched off it still ran at 5.86 TB/s, against
+// 6.6-7.0 TB/s for the bare access pattern (tools/stream_probe.hip); this one measures 6.4-6.7 TB/s.
+// LDS image: [column][16-byte piece], piece p of column c in slot p ^ swz(c), swz(c) = (c & 15) * (pieces / 16):
+// the 16 lanes of a fragment read (16 columns, the same rows) then fall into 16 different slots, i.e. all 64
+// banks once per half-wave (ds_read_b64) or wave (ds_read_b32); the ds_write_b128 of a staged piece covers
+// whole columns.  The non-temporal hint is a template parameter: chosen at run time every load sits behind a
+// branch, the compiler waits for vmcnt(0) where the paths join, and the hint gains nothing (measured).
+// NYC = staged Y columns: 32, 64, or 0 for a self-Gram (A and B fragments both from the X image, tiles on and
+// above the diagonal only).  Windows may be concatenations of blocks (GramArgs segments).  Results: one partial
+// per wave, combined by gram_finalize in a fixed order.
+template <typename R, int TB, int NYC, bool NT>
+__global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
+  using M = Mfma16<R>;
+  using acc_t = typename M::acc_t;
+  constexpr bool SELF = NYC == 0;
+  constexpr int RPU = 16 / (int)sizeof(R);      // rows per 16-byte piece
+  constexpr int NP = TB / 16;                   // pieces per column and tile
+  constexpr int ROWS = NP * RPU;                // rows per tile
+  constexpr int NCOL = NYC + 32;                // staged columns: Y (NYC) then X (32)
+  constexpr int CPL = 64 / NP;                  // columns covered by one load instruction of the wave
+  constexpr int NL = NCOL / CPL;                // loads per lane and tile
+  constexpr int KS = ROWS / 4;                  // MFMA k-steps per tile
+  constexpr int SW = NP / 16;
+  constexpr int PI = SELF ? 2 : NYC / 16, PJ = 2;
+  static_assert(NP >= 16 && NP <= 64 && 64 % NP == 0 && NCOL % CPL == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) char lds[NCOL * TB];
+  typedef R vec_t __attribute__((ext_vector_type(RPU)));
+  const int lane = threadIdx.x;
+  const int p = lane % NP, cl = lane / NP;
+
+  // this lane's piece of staged column q * CPL + cl at row 0 (columns past a window repeat its last one: they
+  // only feed entries that are never written out)
+  const R *colp[NL];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    const int sc = q * CPL + cl;
+    const bool isY = sc < NYC;
+    int c = isY ? sc : sc - NYC;
+    const int mc = isY ? a.my : a.mx;
+    c = c < mc ? c : mc - 1;
+    const GramSeg *segs = isY ? a.ys : a.xs;
+    const int ns = isY ? a.nys : a.nxs;
+    const void *bp = segs[0].p;
+    int64_t ld = segs[0].ld;
+    int c0 = 0;
+#pragma unroll
+    for (int k = 1; k < kGramSegs; ++k)
+      if (k < ns && c >= segs[k].c0) { bp = segs[k].p; ld = segs[k].ld; c0 = segs[k].c0; }
+    colp[q] = reinterpret_cast<const R *>(bp) + (int64_t)(c - c0) * ld + p * RPU;
+  }
+  vec_t regsA[NL], regsB[NL];
+  auto load_tile = [&](int64_t tile, vec_t (&regs)[NL]) {
+    const int64_t row0 = tile * ROWS;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const vec_t *g = reinterpret_cast<const vec_t *>(colp[q] + row0);
+      if constexpr (NT) regs[q] = __builtin_nontemporal_load(g);
+      else regs[q] = *g;
+    }
+  };
+  auto load_tail = [&](int64_t tile, vec_t (&regs)[NL]) {   // the tile with fewer than ROWS rows: zero fill
+    const int64_t row0 = tile * ROWS;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const R *g = colp[q] + row0;
+      vec_t v;
+#pragma unroll
+      for (int e = 0; e < RPU; ++e) v[e] = (row0 + p * RPU + e < a.n) ? g[e] : (R)0;
+      regs[q] = v;
+    }
+  };
+  auto store_tile = [&](const vec_t (&regs)[NL]) {
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      const int sc = q * CPL + cl;
+      *reinterpret_cast<vec_t *>(lds + sc * TB + ((p ^ ((sc & 15) * SW)) << 4)) = regs[q];
+    }
+  };
+  acc_t acc[PI][PJ];
+#pragma unroll
+  for (int i = 0; i < PI; ++i)
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) acc[i][j] = acc_t{(R)0, (R)0, (R)0, (R)0};
+  const int fr = lane & 15, fk = lane >> 4;
+  // byte offset of this lane's fragment element of k-step s inside a column image
+  auto frag_off = [&](int s) -> int {
+    if constexpr (sizeof(R) == 8) return (((2 * s + (fk >> 1)) ^ (fr * SW)) << 4) + (fk & 1) * 8;
+    else return ((s ^ (fr * SW)) << 4) + fk * 4;
+  };
+  auto compute = [&]() {
+#pragma unroll 4
+    for (int s = 0; s < KS; ++s) {
+      const int off = frag_off(s);
+      R fa[PI], fb[PJ];
+#pragma unroll
+      for (int j = 0; j < PJ; ++j) fb[j] = *reinterpret_cast<const R *>(lds + (NYC + j * 16 + fr) * TB + off);
+#pragma unroll
+      for (int i = 0; i < PI; ++i) {
+        if constexpr (SELF) fa[i] = fb[i];
+        else fa[i] = *reinterpret_cast<const R *>(lds + (i * 16 + fr) * TB + off);
+      }
+#pragma unroll
+      for (int i = 0; i < PI; ++i)
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+          if (SELF && i > j) continue;          // symmetric: gram_finalize mirrors the tile below the diagonal
+          acc[i][j] = M::run(fa[i], fb[j], acc[i][j]);
+        }
+    }
+  };
+
+  // Tile j of this wave is t0 + j G; loads past its last tile re-read that tile (an L2 hit) and are dropped, so
+  // the loop body is straight-line code and the compiler waits with counted vmcnt for the older set only.
+  const int64_t nfull = a.n / ROWS, G = gridDim.x, t0 = blockIdx.x;
+  const int64_t count = t0 < nfull ? (nfull - t0 + G - 1) / G : 0;
+  auto tile_of = [&](int64_t j) -> int64_t { return t0 + (j < count ? j : count - 1) * G; };
+  if (count > 0) {
+    load_tile(tile_of(0), regsA);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(tile_of(1), regsB);
+    __builtin_amdgcn_sched_barrier(0);
+    int64_t i = 0;
+    for (; i + 1 < count; i += 2) {
+      store_tile(regsA);
+      __builtin_amdgcn_wave_barrier();
+      load_tile(tile_of(i + 2), regsA);
+      compute();
+      __builtin_amdgcn_wave_barrier();
+      store_tile(regsB);
+      __builtin_amdgcn_wave_barrier();
+      load_tile(tile_of(i + 3), regsB);
+      compute();
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (i < count) {
+      store_tile(regsA);
+      __builtin_amdgcn_wave_barrier();
+      compute();
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (nfull * ROWS < a.n && nfull % G == blockIdx.x) {
+    load_tail(nfull, regsA);
+    store_tile(regsA);
+    __builtin_amdgcn_wave_barrier();
+    compute();
+  }
+  R *out = reinterpret_cast<R *>(a.partials) + blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < PI; ++i)
+#pragma unroll
+    for (int j = 0; j < PJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (SELF && i > j) continue;
+        const int ii = i * 16 + M::out_row(lane, r), jj = j * 16 + (lane & 15);
+        out[(int64_t)(ii * 32 + jj) * gridDim.x] = acc[i][j][r];
+      }
+}
+
+// my <= 64 (32 for a self-Gram), mx <= 32, every segment 16-byte aligned; a.xs / a.ys / a.nxs / a.nys describe the
+// windows, a.same a self-Gram of one block.
+template <int DT, int TB>
+static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) {
+  using R = typename DType<DT>::R;
+  Context &c = ctx();
+  constexpr int ROWS = TB / (int)sizeof(R);
+  const bool self = a.same;
+  const int nyc = self ? 0 : (my <= 32 ? 32 : 64);
+  const int lds_per_wave = (nyc + 32) * TB;
+  // one wave per SIMD: with two register sets in flight per wave more waves only widen the window of rows the chip
+  // works on at once (measured 6.3 TB/s at 4 waves per CU, 6.2 at 8, 4.8 at 2; RLH_GRAM_STREAM_WAVES, tunable)
+  int per_cu = self ? 8 : 4;                     // (a self-Gram tile is half as many bytes: twice the waves)
+  const char *e = getenv("RLH_GRAM_STREAM_WAVES");
+  if (e && *e && atoi(e) > 0) per_cu = atoi(e);
+  if (per_cu > 160 * 1024 / lds_per_wave) per_cu = 160 * 1024 / lds_per_wave;
+  int64_t nbx = (int64_t)c.num_cu * per_cu;
+  const int64_t ntiles = (a.n + ROWS - 1) / ROWS;
+  if (nbx > ntiles) nbx = ntiles;
+  if (nbx < 1) nbx = 1;
+  const int VY = self ? 32 : nyc;
+  RLH_REQUIRE((size_t)nbx * VY * 32 * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
+#define RLH_GS(NYC_)                                                                                             \
+  do {                                                                                                           \
+    if (a.nt & 1)                                                                                                \
+      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, true>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a);  \
+    else                                                                                                         \
+      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, false>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a); \
+  } while (0)
+  if (nyc == 0) RLH_GS(0); else if (nyc == 32) RLH_GS(32); else RLH_GS(64);
+#undef RLH_GS
+  RLH_HIP(hipGetLastError());
+  const int total = (int)(my * mx);
+  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nbx, 1, VY, 32,
+                     (int)my, (int)mx, d_out, a.same);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int DT>
 static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t my, const void *Y, int64_t ldy,
                      void *d_out) {
@@ -475,7 +694,21 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   a.same = (X == Y && ldx == ldy && mx == my) ? 1 : 0;
   a.npj = npj; a.partials = c.work;
   const int64_t es = dtype_size(DT);
+  a.nt = gram_nt(n * (a.same ? mx : mx + my) * es);
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
+  if constexpr (!DType<DT>::cplx) {
+    // real blocks, 17 .. 32 columns on the X side and up to 64 on the Y side: the wave-private streaming kernel
+    // (RLH_GRAM_STREAM=0: the workgroup kernel; =256 / 512: bytes per column and tile)
+    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 256;
+    if (stream && aligned && mx <= 32 && (a.same ? my <= 32 : my <= 64) && (mx > 16 || my > 16)) {
+      a.npj = 1;
+      a.nxs = a.nys = 1;
+      a.xs[0] = GramSeg{X, ldx, 0};
+      a.ys[0] = GramSeg{Y, ldy, 0};
+      for (int k = 1; k < kGramSegs; ++k) a.xs[k] = a.ys[k] = GramSeg{nullptr, 0, 1 << 30};
+      return stream == 512 ? gram_stream_launch<DT, 512>(a, my, mx, d_out) : gram_stream_launch<DT, 256>(a, my, mx, d_out);
+    }
+  }
   // Kernel variant (see gram_kernel).  Measured at n = 10^7, m = 32 fp64: the two-chunk pipeline
   // gains 5 % on the self-Gram (0.50 -> 0.475 ms) and nothing on the two-operand Gram (0.885 vs
   // 0.868 ms in sustained use: RLH_GRAM_PIPE=2 selects it); 1 KiB column pieces gain 2.5 % on the
@@ -555,6 +788,14 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
   const int npi = (vy + PI * 16 - 1) / (PI * 16), npj = (vx + PJ * 16 - 1) / (PJ * 16);
   a.X = X[0]; a.Y = Y[0]; a.ldx = ldx[0]; a.ldy = ldy[0]; a.n = n; a.mx = (int)mxt; a.my = (int)myt;
   a.same = 0; a.npj = npj; a.partials = c.work;
+  a.nt = gram_nt(n * (mxt + myt) * es);
+  if constexpr (!DType<DT>::cplx) {
+    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 256;
+    if (stream && aligned && mxt <= 32 && myt <= 64 && (mxt > 16 || myt > 16)) {
+      a.npj = 1;
+      return stream == 512 ? gram_stream_launch<DT, 512>(a, myt, mxt, d_out) : gram_stream_launch<DT, 256>(a, myt, mxt, d_out);
+    }
+  }
   const int ROWS = 512 / (int)sizeof(R);
   a.nchunks = (n + ROWS - 1) / ROWS;
 #define RLH_GRAM_MCASE(pi, pj)                                                                        \
@@ -571,24 +812,54 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
 
 // ---------------------------------------------------------------- dots (K2)
 // One workgroup per (row block, column); deterministic two-stage reduction.
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(256) void dots_kernel(const T *X, int64_t ldx, const T *Y, int64_t ldy, int64_t n,
-                                                   T *partials, int nbx) {
+                                                   T *partials, int nbx, int per) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int col = blockIdx.y;
   const T *x = X + (int64_t)col * ldx;
   const T *y = Y + (int64_t)col * ldy;
   T acc = zero_of(T{});
-  const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
-  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
-    if (ALIGNED && r + VEC <= n) {
-      struct alignas(16) V { T v[VEC]; };
-      const V xv = *reinterpret_cast<const V *>(x + r);
-      const V yv = *reinterpret_cast<const V *>(y + r);
+  // a workgroup owns `per` consecutive runs of 256 16-byte pieces: resident workgroups form a compact window that
+  // sweeps the column front to back (no grid-stride loop: see row_blocks in update.hip)
+  // (`per` is a multiple of 4: groups of four pieces per thread, the eight loads of a complete group issued
+  // before the first multiply)
+  struct alignas(16) V { T v[VEC]; };
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  auto piece = [&](const T *p) -> V {
+    union { u4 u; V v; } c;
+    if constexpr (NT) c.u = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(p));
+    else c.u = *reinterpret_cast<const u4 *>(p);
+    return c.v;
+  };
+  for (int g = 0; g < per; g += 4) {
+    const int64_t base = ((int64_t)blockIdx.x * per + g) * 256 * VEC;
+    if (base >= n) break;
+    if (ALIGNED && base + 4 * 256 * VEC <= n && x == y) {        // X.dots(X): every piece is loaded once
+      V xv[4];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) fma_conj_acc(acc, yv.v[e], xv.v[e]);
+      for (int i = 0; i < 4; ++i) xv[i] = piece(x + base + ((int64_t)i * 256 + threadIdx.x) * VEC);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fma_conj_acc(acc, xv[i].v[e], xv[i].v[e]);
+    } else if (ALIGNED && base + 4 * 256 * VEC <= n) {
+      V xv[4], yv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t r = base + ((int64_t)i * 256 + threadIdx.x) * VEC;
+        xv[i] = piece(x + r);
+        yv[i] = piece(y + r);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fma_conj_acc(acc, yv[i].v[e], xv[i].v[e]);
     } else {
-      for (int e = 0; e < VEC && r + e < n; ++e) fma_conj_acc(acc, y[r + e], x[r + e]);
+      for (int i = 0; i < 4; ++i) {
+        const int64_t r = base + ((int64_t)i * 256 + threadIdx.x) * VEC;
+        for (int e = 0; e < VEC && r + e < n; ++e) fma_conj_acc(acc, y[r + e], x[r + e]);
+      }
     }
   }
   __shared__ T red[256];
@@ -654,19 +925,26 @@ static int dots_impl(int64_t n, int64_t m, const void *X, int64_t ldx, const voi
   using T = typename DType<DT>::T;
   Context &c = ctx();
   constexpr int VEC = 16 / (int)sizeof(T);
-  int64_t nbx = (n + 256 * VEC * 4 - 1) / (256 * VEC * 4);     // >= 4 vector loads per thread
-  const int64_t cap = ((int64_t)c.num_cu * 8 + m - 1) / m;
-  if (nbx > cap) nbx = cap;
+  int per = 4;                                                 // vector loads per thread
+  int64_t nbx = (n + 256 * VEC * (int64_t)per - 1) / (256 * VEC * (int64_t)per);
+  while (nbx > 1 && ((size_t)nbx * m * sizeof(T) > kWorkspaceBytes / 4 || nbx > 0x7fffffff)) {
+    per *= 2;
+    nbx = (n + 256 * VEC * (int64_t)per - 1) / (256 * VEC * (int64_t)per);
+  }
   if (nbx < 1) nbx = 1;
   RLH_REQUIRE((size_t)nbx * m * sizeof(T) <= kWorkspaceBytes, "rlh_dots: too many columns");
+  const int nt = gram_nt(n * m * (int64_t)sizeof(T) * (X == Y ? 1 : 2));
   const bool aligned = aligned16(X, ldx, sizeof(T)) && aligned16(Y, ldy, sizeof(T));
   dim3 grid((unsigned)nbx, (unsigned)m);
-  if (aligned)
-    hipLaunchKernelGGL((dots_kernel<T, true>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
-                       n, (T *)c.work, (int)nbx);
+  if (aligned && (nt & 1))
+    hipLaunchKernelGGL((dots_kernel<T, true, true>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
+                       n, (T *)c.work, (int)nbx, per);
+  else if (aligned)
+    hipLaunchKernelGGL((dots_kernel<T, true, false>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
+                       n, (T *)c.work, (int)nbx, per);
   else
-    hipLaunchKernelGGL((dots_kernel<T, false>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
-                       n, (T *)c.work, (int)nbx);
+    hipLaunchKernelGGL((dots_kernel<T, false, false>), grid, dim3(256), 0, c.stream, (const T *)X, ldx, (const T *)Y, ldy,
+                       n, (T *)c.work, (int)nbx, per);
   RLH_HIP(hipGetLastError());
   hipLaunchKernelGGL((dots_finalize<T>), dim3(((int)m + 3) / 4), dim3(256), 0, c.stream, (const T *)c.work,
                      (int)nbx, (int)m, (T *)d_out);

@@ -29,7 +29,35 @@ static int env_flag(const char *name, int dflt) {
 // lane, which the vector-memory path retires at up to twice the bytes per cycle of 8-byte accesses.
 template <typename T, int RV> struct alignas(RV * sizeof(T) >= 16 ? 16 : sizeof(T)) RowVec { T e[RV]; };
 
-template <typename T, int JT, bool BETA, int RV>
+// 16-byte accesses with or without the non-temporal hint (experiment switch RLH_UPDATE_NT: bit 0 loads, bit 1 stores)
+typedef unsigned upd_u4 __attribute__((ext_vector_type(4)));
+// (the hint is a TEMPLATE parameter: chosen at run time, every access sits behind a branch and the compiler
+// waits for vmcnt(0) where the paths join -- measured on the Gram kernel: no gain from the hint at all)
+template <bool NT, typename V> __device__ __forceinline__ V load16(const V *p) {
+  static_assert(sizeof(V) == 16, "16-byte pieces");
+  union { upd_u4 u; V v; } c;
+  if constexpr (NT) c.u = __builtin_nontemporal_load(reinterpret_cast<const upd_u4 *>(p));
+  else c.u = *reinterpret_cast<const upd_u4 *>(p);
+  return c.v;
+}
+template <bool NT, typename V> __device__ __forceinline__ void store16(V *p, const V &v) {
+  static_assert(sizeof(V) == 16, "16-byte pieces");
+  union { upd_u4 u; V v; } c;
+  c.v = v;
+  if constexpr (NT) __builtin_nontemporal_store(c.u, reinterpret_cast<upd_u4 *>(p));
+  else *reinterpret_cast<upd_u4 *>(p) = c.u;
+}
+
+template <bool ALIGNED, bool NT, typename V> __device__ __forceinline__ V ldv(const V *p) {
+  if constexpr (ALIGNED) return load16<NT>(p);
+  else return *p;
+}
+template <bool ALIGNED, bool NT, typename V> __device__ __forceinline__ void stv(V *p, const V &v) {
+  if constexpr (ALIGNED) store16<NT>(p, v);
+  else *p = v;
+}
+
+template <typename T, int JT, bool BETA, int RV, bool NT>
 __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__ X, int64_t ldx,
                                                            const T *__restrict__ X2, int64_t ldx2, int k2, int kpad,
                                                            T *__restrict__ Out, int64_t ldo,
@@ -45,21 +73,22 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
     const int gj = j0 + j;
     return gj < msplit ? Out + (int64_t)gj * ldo : Out2 + (int64_t)(gj - msplit) * ldo2;
   };
-  const int64_t stride = (int64_t)gridDim.x * 256 * RV;
-  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV; row - (int64_t)(threadIdx.x & 63) * RV < n; row += stride) {
+  // one row group per lane, no loop: the grid covers every row (launch_update_rv), so the resident workgroups are a
+  // compact window sweeping the blocks front to back
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV, once = 0; once < 1; ++once) {
     // every row group of the wave is complete (wave-uniform): straight-line loads, the columns of X
     // in a two-stage register pipeline -- the loads of the next kUnrollK columns are in flight during
     // the FMAs of the current ones (with one predicate per load the compiler put every load behind a
     // branch and an s_waitcnt vmcnt(0) in front of the FMAs: nothing overlapped inside a wave)
     const int64_t wave_row0 = row - (int64_t)(threadIdx.x & 63) * RV;
-    if (RV > 1 && wave_row0 + 64 * RV <= n) {
+    if constexpr (RV > 1) if (wave_row0 + 64 * RV <= n) {
       T acc[RV][JT];
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
 #pragma unroll
         for (int r = 0; r < RV; ++r) acc[r][j] = zero_of(T{});
         if (BETA && j < jv) {
-          const V o = *reinterpret_cast<const V *>(out_col(j) + row);
+          const V o = load16<NT>(reinterpret_cast<const V *>(out_col(j) + row));
 #pragma unroll
           for (int r = 0; r < RV; ++r) acc[r][j] = o.e[r];
         }
@@ -71,7 +100,7 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
 #pragma unroll
           for (int u = 0; u < kUnrollK; ++u) {
             const int col = (i + u) < kk ? (i + u) : (kk - 1);       // Q rows >= kk are zero
-            x[u] = *reinterpret_cast<const V *>(S + row + (int64_t)col * lds_);
+            x[u] = load16<NT>(reinterpret_cast<const V *>(S + row + (int64_t)col * lds_));
           }
         };
         auto fma = [&](const V (&x)[kUnrollK], int i) {
@@ -100,7 +129,7 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
           V o;
 #pragma unroll
           for (int r = 0; r < RV; ++r) o.e[r] = acc[r][j];
-          *reinterpret_cast<V *>(out_col(j) + row) = o;
+          store16<NT>(reinterpret_cast<V *>(out_col(j) + row), o);
         }
       continue;
     }
@@ -177,20 +206,33 @@ template <> struct HostScalar<c64> {
   static c64 mul(const double *a, c64 q) { return c64{a[0] * q.re - a[1] * q.im, a[0] * q.im + a[1] * q.re}; }
 };
 
+// non-temporal hint on the block update's loads and stores: RLH_UPDATE_NT = 0 / 1 forces, else for operands beyond
+// the Infinity Cache
+static int update_nt(int64_t bytes) {
+  const char *e = getenv("RLH_UPDATE_NT");
+  if (e && *e) return atoi(e) != 0;
+  return bytes > ((int64_t)192 << 20);
+}
+
 template <typename T, int JT, int RV>
 static int launch_update_rv(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
                             int beta, const T *X2, int64_t ldx2, int k2, int kpad, T *Out2, int64_t ldo2, int msplit) {
   Context &c = ctx();
   int64_t nbx = ((n + RV - 1) / RV + 255) / 256;
-  const int64_t cap = (int64_t)c.num_cu * 8;
-  if (nbx > cap) nbx = cap;
+  // one row group per lane and no loop (see row_blocks below)
+  RLH_REQUIRE(nbx <= 0x7fffffff, "rlh_block_update: %lld rows exceed the grid", (long long)n);
   dim3 grid((unsigned)nbx, (unsigned)((m + JT - 1) / JT));
-  if (beta)
-    hipLaunchKernelGGL((block_update_kernel<T, JT, true, RV>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
-                       Out, ldo, Qd, ldq, n, k, m, Out2, ldo2, msplit);
-  else
-    hipLaunchKernelGGL((block_update_kernel<T, JT, false, RV>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad,
-                       Out, ldo, Qd, ldq, n, k, m, Out2, ldo2, msplit);
+  const int nt = update_nt((int64_t)n * (k + k2 + (beta ? 2 : 1) * m) * (int64_t)sizeof(T));
+#define RLH_UPD(BETA_, NT_)                                                                                              \
+  hipLaunchKernelGGL((block_update_kernel<T, JT, BETA_, RV, NT_>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad, \
+                     Out, ldo, Qd, ldq, n, k, m, Out2, ldo2, msplit)
+  if constexpr (RV > 1) {
+    if (nt) { if (beta) RLH_UPD(true, true); else RLH_UPD(false, true); }
+    else { if (beta) RLH_UPD(true, false); else RLH_UPD(false, false); }
+  } else {
+    if (beta) RLH_UPD(true, false); else RLH_UPD(false, false);
+  }
+#undef RLH_UPD
   RLH_HIP(hipGetLastError());
   return 0;
 }
@@ -331,6 +373,11 @@ static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, cons
   return 0;
 }
 
+// (A matrix-core version of the REAL update -- X fragments loaded in MFMA layout, 16 lanes x 16 bytes per column --
+// was measured and dropped: 1.16-1.30 ms against 1.02 ms for the multiply at n = 215^3, m = k = 32 fp64.  The real
+// update is bound by its 64 interleaved column streams, not by arithmetic: the same loads and stores with no
+// arithmetic at all run at the same rate, tools/stream_probe.hip, and 256-byte runs stream slower than 1-KB runs.)
+
 template <typename T> struct IsComplex { static constexpr bool value = false; };
 template <> struct IsComplex<c32> { static constexpr bool value = true; };
 template <> struct IsComplex<c64> { static constexpr bool value = true; };
@@ -449,7 +496,7 @@ static int block_update2_impl(int64_t n, int64_t k1, const void *X1_, int64_t ld
 }
 
 // Out[:, i] = a[i] * A[:, i] + b[i] * B[:, i]   (residual W = AX - X diag(lmd) in one pass)
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(256) void lincomb_cols_kernel(const T *A, int64_t lda,
                                                            const T *B, int64_t ldb, T *Out,
                                                            int64_t ldo, const T *__restrict__ coef, int m, int64_t n) {
@@ -463,8 +510,8 @@ __global__ __launch_bounds__(256) void lincomb_cols_kernel(const T *A, int64_t l
   const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
   for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
     if (r + VEC <= n) {
-      const V av = *reinterpret_cast<const V *>(a + r);
-      const V bv = *reinterpret_cast<const V *>(b + r);
+      const V av = ldv<ALIGNED, NT>(reinterpret_cast<const V *>(a + r));
+      const V bv = ldv<ALIGNED, NT>(reinterpret_cast<const V *>(b + r));
       V ov;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256) void lincomb_cols_kernel(const T *A, int64_t l
         fma_acc(t, cb, bv.v[e]);
         ov.v[e] = t;
       }
-      *reinterpret_cast<V *>(o + r) = ov;
+      stv<ALIGNED, NT>(reinterpret_cast<V *>(o + r), ov);
     } else {
       for (int e = 0; e < VEC && r + e < n; ++e) {
         T t = mul_of(ca, a[r + e]);
@@ -486,7 +533,7 @@ __global__ __launch_bounds__(256) void lincomb_cols_kernel(const T *A, int64_t l
 // ---------------------------------------------------------------- column-wise elementwise kernels
 // grid = (row blocks, columns); VEC elements (16 bytes) per lane when aligned.
 
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(256) void axpy_cols_kernel(const T *__restrict__ X, int64_t ldx, T *__restrict__ Y,
                                                         int64_t ldy, const T *__restrict__ s, int64_t n) {
   constexpr int VEC = ALIGNED ? 16 / (int)sizeof(T) : 1;
@@ -498,11 +545,11 @@ __global__ __launch_bounds__(256) void axpy_cols_kernel(const T *__restrict__ X,
   const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
   for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
     if (r + VEC <= n) {
-      const V xv = *reinterpret_cast<const V *>(x + r);
-      V yv = *reinterpret_cast<const V *>(y + r);
+      const V xv = ldv<ALIGNED, NT>(reinterpret_cast<const V *>(x + r));
+      V yv = ldv<ALIGNED, NT>(reinterpret_cast<const V *>(y + r));
 #pragma unroll
       for (int e = 0; e < VEC; ++e) fma_acc(yv.v[e], a, xv.v[e]);
-      *reinterpret_cast<V *>(y + r) = yv;
+      stv<ALIGNED, NT>(reinterpret_cast<V *>(y + r), yv);
     } else {
       for (int e = 0; e < VEC && r + e < n; ++e) {
         T t = y[r + e];
@@ -513,7 +560,7 @@ __global__ __launch_bounds__(256) void axpy_cols_kernel(const T *__restrict__ X,
   }
 }
 
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(256) void scale_cols_kernel(T *__restrict__ X, int64_t ldx, const T *__restrict__ s,
                                                          int64_t n) {
   constexpr int VEC = ALIGNED ? 16 / (int)sizeof(T) : 1;
@@ -524,10 +571,10 @@ __global__ __launch_bounds__(256) void scale_cols_kernel(T *__restrict__ X, int6
   const int64_t stride = (int64_t)gridDim.x * 256 * VEC;
   for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; r < n; r += stride) {
     if (r + VEC <= n) {
-      V xv = *reinterpret_cast<const V *>(x + r);
+      V xv = ldv<ALIGNED, NT>(reinterpret_cast<const V *>(x + r));
 #pragma unroll
       for (int e = 0; e < VEC; ++e) xv.v[e] = mul_of(xv.v[e], a);
-      *reinterpret_cast<V *>(x + r) = xv;
+      stv<ALIGNED, NT>(reinterpret_cast<V *>(x + r), xv);
     } else {
       for (int e = 0; e < VEC && r + e < n; ++e) x[r + e] = mul_of(x[r + e], a);
     }
@@ -634,13 +681,30 @@ __global__ __launch_bounds__(256) void bf16_unpack_kernel(const unsigned short *
     y[r] = (TD)__uint_as_float((unsigned)x[r] << 16);
 }
 
+// One item per lane and NO loop for the column-wise kernels: workgroups are dispatched in index order, so the
+// set of resident ones is a compact window that sweeps each column front to back -- the access order HBM likes
+// best.  Measured on a 2.5 GB fp64 block (tools/stream_probe.hip): copy 6.0 TB/s (6.6 with the non-temporal
+// hint) against 5.4-5.6 for a capped grid whose workgroups stride through the column, 4.3-5.0 for a
+// grid-stride loop over the whole block.  RLH_ROW_BLOCKS_PER_CU > 0 restores a capped grid (experiments).
 static inline unsigned row_blocks(int64_t items, int64_t m) {
-  Context &c = ctx();
-  int64_t nb = (items + 256 * 4 - 1) / (256 * 4);            // ~4 items per lane
-  const int64_t cap = ((int64_t)c.num_cu * 16 + m - 1) / m;
-  if (nb > cap) nb = cap;
+  int64_t nb = (items + 255) / 256;
+  const int per_cu = env_flag("RLH_ROW_BLOCKS_PER_CU", 0);
+  if (per_cu > 0) {
+    const int64_t cap = ((int64_t)ctx().num_cu * per_cu + m - 1) / m;
+    if (nb > cap) nb = cap;
+  }
+  if (nb > 0x7fffffff) nb = 0x7fffffff;
   if (nb < 1) nb = 1;
   return (unsigned)nb;
+}
+
+// Non-temporal loads / stores for blocks that cannot stay in the 256 MB Infinity Cache until their next use
+// (RLH_STREAM_NT = 0 / 1 forces): +5-8 % on every streaming kernel at the roofline block size, while small
+// blocks keep the default policy and are found cached by the next kernel.
+static inline int stream_nt(int64_t bytes) {
+  const char *e = getenv("RLH_STREAM_NT");
+  if (e && *e) return atoi(e) != 0;
+  return bytes > (int64_t)192 << 20;
 }
 
 // stages m per-column coefficients of type T into the ring
@@ -665,11 +729,14 @@ static int axpy_cols_impl(int64_t n, int64_t m, const void *s_, bool broadcast, 
   const bool al = aligned16(X, ldx, sizeof(T)) && aligned16(Y, ldy, sizeof(T));
   const int vec = al ? 16 / (int)sizeof(T) : 1;
   dim3 grid(row_blocks((n + vec - 1) / vec, m), (unsigned)m);
-  if (al)
-    hipLaunchKernelGGL((axpy_cols_kernel<T, true>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y, ldy,
-                       sd, n);
+  if (al && stream_nt(3 * n * m * (int64_t)sizeof(T)))
+    hipLaunchKernelGGL((axpy_cols_kernel<T, true, true>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y,
+                       ldy, sd, n);
+  else if (al)
+    hipLaunchKernelGGL((axpy_cols_kernel<T, true, false>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y,
+                       ldy, sd, n);
   else
-    hipLaunchKernelGGL((axpy_cols_kernel<T, false>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y,
+    hipLaunchKernelGGL((axpy_cols_kernel<T, false, false>), grid, dim3(256), 0, ctx().stream, (const T *)X, ldx, (T *)Y,
                        ldy, sd, n);
   RLH_HIP(hipGetLastError());
   return ring_release(slot);
@@ -685,11 +752,14 @@ static int lincomb_cols_impl(int64_t n, int64_t m, const void *a_, const void *A
   const bool al = aligned16(A, lda, sizeof(T)) && aligned16(B, ldb, sizeof(T)) && aligned16(Out, ldo, sizeof(T));
   const int vec = al ? 16 / (int)sizeof(T) : 1;
   dim3 grid(row_blocks((n + vec - 1) / vec, m), (unsigned)m);
-  if (al)
-    hipLaunchKernelGGL((lincomb_cols_kernel<T, true>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
+  if (al && stream_nt(3 * n * m * (int64_t)sizeof(T)))
+    hipLaunchKernelGGL((lincomb_cols_kernel<T, true, true>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
+                       (const T *)B, ldb, (T *)Out, ldo, cd, (int)m, n);
+  else if (al)
+    hipLaunchKernelGGL((lincomb_cols_kernel<T, true, false>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
                        (const T *)B, ldb, (T *)Out, ldo, cd, (int)m, n);
   else
-    hipLaunchKernelGGL((lincomb_cols_kernel<T, false>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
+    hipLaunchKernelGGL((lincomb_cols_kernel<T, false, false>), grid, dim3(256), 0, ctx().stream, (const T *)A, lda,
                        (const T *)B, ldb, (T *)Out, ldo, cd, (int)m, n);
   RLH_HIP(hipGetLastError());
   return ring_release(slot);
@@ -716,10 +786,12 @@ static int scale_cols_impl(int64_t n, int64_t m, const double *s, int mode, void
   const bool al = aligned16(X, ldx, sizeof(T));
   const int vec = al ? 16 / (int)sizeof(T) : 1;
   dim3 grid(row_blocks((n + vec - 1) / vec, m), (unsigned)m);
-  if (al)
-    hipLaunchKernelGGL((scale_cols_kernel<T, true>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
+  if (al && stream_nt(2 * n * m * (int64_t)sizeof(T)))
+    hipLaunchKernelGGL((scale_cols_kernel<T, true, true>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
+  else if (al)
+    hipLaunchKernelGGL((scale_cols_kernel<T, true, false>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
   else
-    hipLaunchKernelGGL((scale_cols_kernel<T, false>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
+    hipLaunchKernelGGL((scale_cols_kernel<T, false, false>), grid, dim3(256), 0, ctx().stream, (T *)X, ldx, sd, n);
   RLH_HIP(hipGetLastError());
   return ring_release(slot);
 }
@@ -738,7 +810,7 @@ static int copy_cols_impl(int dtype, int64_t n, int64_t m, const int64_t *ind, c
     const int64_t nw = n * es / 16;
     dim3 grid(row_blocks(nw, m), (unsigned)m);
     hipLaunchKernelGGL((copy_cols_kernel<W16>), grid, dim3(256), 0, ctx().stream, (const W16 *)X, ldx * es / 16,
-                       (W16 *)Y, ldy * es / 16, indd, nw, (int)((n * es % 16) / 4), env_flag("RLH_COPY_NT", 1));
+                       (W16 *)Y, ldy * es / 16, indd, nw, (int)((n * es % 16) / 4), stream_nt(2 * n * m * es));
   } else if (es % 8 == 0) {
     const int64_t nw = n * es / 8;
     dim3 grid(row_blocks(nw, m), (unsigned)m);
