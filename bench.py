@@ -552,6 +552,16 @@ def main():
             _lib.check(L.rlh_free(rbuf))
             res['gram_ms'] = ms.value / reps
             res['gram_bytes'] = 2 * nloc * m * es
+            # device-copy ceiling of this box ("first measure a device-copy ceiling on the box and
+            # report both"): one block copied onto another, read + write bytes, same event timing
+            W = blocks[6]
+            cp = lambda: L.rlh_copy(code, nloc, m, X.data_ptr(), X.ld(), W.data_ptr(), W.ld())
+            _lib.check(cp())
+            _lib.check(L.rlh_timer_start())
+            for _ in range(reps):
+                _lib.check(cp())
+            _lib.check(L.rlh_timer_stop(ctypes.byref(ms)))
+            res['copy_gbs'] = 2 * nloc * m * es / (max(ms.value, 1e-9) / reps * 1e-3) / 1e9
         return res
 
     main_res = run_mode(args.scaling, args.steps, args.warmup, True)
@@ -570,11 +580,13 @@ def main():
             traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
-    roofline = {'bound': 'hbm', 'kernel': 'gram_kernel<fp64, 2x2 tiles> (X.dot(Y), m=k=%d)' % m,
+    roofline = {'bound': 'hbm', 'kernel': 'gram_stream_kernel<double, 256, 32> (X.dot(Y), m=k=%d)' % m,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': main_res['gram_bytes'], 'avg_launch_ms': round(main_res['gram_ms'], 4),
-                'inner_iteration_frac': round(main_res['value'] / world / HBM_PEAK_GBS, 4)}
+                'inner_iteration_frac': round(main_res['value'] / world / HBM_PEAK_GBS, 4),
+                'device_copy_ceiling_gbs': round(main_res.get('copy_gbs', 0.0), 1),
+                'frac_of_copy_ceiling': round(achieved / max(main_res.get('copy_gbs', 0.0), 1e-9), 4)}
     n, nnz, nzg = main_res['n'], main_res['nnz'], main_res['nzg']
     out = {'metric': 'inner-iter GB/s vs HBM roofline (Gram+dots+SpMM of one block-JCG iteration)',
            'value': round(main_res['value'], 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,

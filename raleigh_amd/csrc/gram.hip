@@ -491,7 +491,7 @@ static int gram_nt(int64_t bytes) {
 // NYC = staged Y columns: 32, 64, or 0 for a self-Gram (A and B fragments both from the X image, tiles on and
 // above the diagonal only).  Windows may be concatenations of blocks (GramArgs segments).  Results: one partial
 // per wave, combined by gram_finalize in a fixed order.
-template <typename R, int TB, int NYC, bool NT>
+template <typename R, int TB, int NYC, int NXC, bool NT>
 __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
   using M = Mfma16<R>;
   using acc_t = typename M::acc_t;
@@ -499,12 +499,12 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
   constexpr int RPU = 16 / (int)sizeof(R);      // rows per 16-byte piece
   constexpr int NP = TB / 16;                   // pieces per column and tile
   constexpr int ROWS = NP * RPU;                // rows per tile
-  constexpr int NCOL = NYC + 32;                // staged columns: Y (NYC) then X (32)
+  constexpr int NCOL = NYC + NXC;               // staged columns: Y (NYC) then X (NXC = 16 or 32)
   constexpr int CPL = 64 / NP;                  // columns covered by one load instruction of the wave
   constexpr int NL = NCOL / CPL;                // loads per lane and tile
   constexpr int KS = ROWS / 4;                  // MFMA k-steps per tile
   constexpr int SW = NP / 16;
-  constexpr int PI = SELF ? 2 : NYC / 16, PJ = 2;
+  constexpr int PJ = NXC / 16, PI = SELF ? PJ : NYC / 16;
   static_assert(NP >= 16 && NP <= 64 && 64 % NP == 0 && NCOL % CPL == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) char lds[NCOL * TB];
   typedef R vec_t __attribute__((ext_vector_type(RPU)));
@@ -514,12 +514,16 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
   // this lane's piece of staged column q * CPL + cl at row 0 (columns past a window repeat its last one: they
   // only feed entries that are never written out)
   const R *colp[NL];
+  int tstep[NL];                                // rows a tile advances this lane's piece by: ROWS, or 0 past the window
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
     const int sc = q * CPL + cl;
     const bool isY = sc < NYC;
     int c = isY ? sc : sc - NYC;
     const int mc = isY ? a.my : a.mx;
+    // staged columns past the window feed only entries that are never written out: their lanes re-read ONE
+    // piece (row 0 of the window's last column, an L1 hit) instead of streaming a duplicate of that column
+    tstep[q] = c < mc ? ROWS : 0;
     c = c < mc ? c : mc - 1;
     const GramSeg *segs = isY ? a.ys : a.xs;
     const int ns = isY ? a.nys : a.nxs;
@@ -533,10 +537,9 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
   }
   vec_t regsA[NL], regsB[NL];
   auto load_tile = [&](int64_t tile, vec_t (&regs)[NL]) {
-    const int64_t row0 = tile * ROWS;
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
-      const vec_t *g = reinterpret_cast<const vec_t *>(colp[q] + row0);
+      const vec_t *g = reinterpret_cast<const vec_t *>(colp[q] + tile * tstep[q]);
       if constexpr (NT) regs[q] = __builtin_nontemporal_load(g);
       else regs[q] = *g;
     }
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
     const int64_t row0 = tile * ROWS;
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
-      const R *g = colp[q] + row0;
+      const R *g = colp[q] + tile * tstep[q];
       vec_t v;
 #pragma unroll
       for (int e = 0; e < RPU; ++e) v[e] = (row0 + p * RPU + e < a.n) ? g[e] : (R)0;
@@ -637,23 +640,27 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
       for (int r = 0; r < 4; ++r) {
         if (SELF && i > j) continue;
         const int ii = i * 16 + M::out_row(lane, r), jj = j * 16 + (lane & 15);
-        out[(int64_t)(ii * 32 + jj) * gridDim.x] = acc[i][j][r];
+        out[(int64_t)(ii * NXC + jj) * gridDim.x] = acc[i][j][r];
       }
 }
 
 // my <= 64 (32 for a self-Gram), mx <= 32, every segment 16-byte aligned; a.xs / a.ys / a.nxs / a.nys describe the
 // windows, a.same a self-Gram of one block.
-template <int DT, int TB>
+template <int DT>
 static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) {
   using R = typename DType<DT>::R;
   Context &c = ctx();
+  constexpr int TB = 256;
   constexpr int ROWS = TB / (int)sizeof(R);
   const bool self = a.same;
-  const int nyc = self ? 0 : (my <= 32 ? 32 : 64);
-  const int lds_per_wave = (nyc + 32) * TB;
-  // one wave per SIMD: with two register sets in flight per wave more waves only widen the window of rows the chip
-  // works on at once (measured 6.3 TB/s at 4 waves per CU, 6.2 at 8, 4.8 at 2; RLH_GRAM_STREAM_WAVES, tunable)
-  int per_cu = self ? 8 : 4;                     // (a self-Gram tile is half as many bytes: twice the waves)
+  const int nxc = mx <= 16 ? 16 : 32;
+  const int nyc = self ? 0 : (my <= 16 ? 16 : (my <= 32 ? 32 : 64));
+  const int lds_per_wave = (nyc + nxc) * TB;
+  // One wave per SIMD where a tile is 16 KB (64 staged columns) or more: with two register sets in flight per wave
+  // more waves only widen the window of rows the chip works on at once (measured 6.3 TB/s at 4 waves per CU, 6.2 at
+  // 8, 4.8 at 2); narrower tiles take proportionally more waves.  RLH_GRAM_STREAM_WAVES: tunable.
+  int per_cu = 65536 / lds_per_wave;             // 64 staged columns: 4, 32: 8, 16: 16 (two sets of a tile each in flight)
+  per_cu = per_cu < 4 ? 4 : (per_cu + 1) & ~1;
   const char *e = getenv("RLH_GRAM_STREAM_WAVES");
   if (e && *e && atoi(e) > 0) per_cu = atoi(e);
   if (per_cu > 160 * 1024 / lds_per_wave) per_cu = 160 * 1024 / lds_per_wave;
@@ -661,20 +668,24 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   const int64_t ntiles = (a.n + ROWS - 1) / ROWS;
   if (nbx > ntiles) nbx = ntiles;
   if (nbx < 1) nbx = 1;
-  const int VY = self ? 32 : nyc;
-  RLH_REQUIRE((size_t)nbx * VY * 32 * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
-#define RLH_GS(NYC_)                                                                                             \
-  do {                                                                                                           \
-    if (a.nt & 1)                                                                                                \
-      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, true>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a);  \
-    else                                                                                                         \
-      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, false>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a); \
+  const int VY = self ? nxc : nyc;
+  RLH_REQUIRE((size_t)nbx * VY * nxc * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
+#define RLH_GS(NYC_, NXC_)                                                                                             \
+  do {                                                                                                                 \
+    if (a.nt & 1)                                                                                                      \
+      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, true>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a);  \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, false>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a); \
   } while (0)
-  if (nyc == 0) RLH_GS(0); else if (nyc == 32) RLH_GS(32); else RLH_GS(64);
+  if (nxc == 16) {
+    if (nyc == 0) RLH_GS(0, 16); else if (nyc == 16) RLH_GS(16, 16); else if (nyc == 32) RLH_GS(32, 16); else RLH_GS(64, 16);
+  } else {
+    if (nyc == 0) RLH_GS(0, 32); else if (nyc == 16) RLH_GS(16, 32); else if (nyc == 32) RLH_GS(32, 32); else RLH_GS(64, 32);
+  }
 #undef RLH_GS
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
-  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nbx, 1, VY, 32,
+  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nbx, 1, VY, nxc,
                      (int)my, (int)mx, d_out, a.same);
   RLH_HIP(hipGetLastError());
   return 0;
@@ -697,16 +708,16 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   a.nt = gram_nt(n * (a.same ? mx : mx + my) * es);
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
   if constexpr (!DType<DT>::cplx) {
-    // real blocks, 17 .. 32 columns on the X side and up to 64 on the Y side: the wave-private streaming kernel
-    // (RLH_GRAM_STREAM=0: the workgroup kernel; =256 / 512: bytes per column and tile)
-    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 256;
-    if (stream && aligned && mx <= 32 && (a.same ? my <= 32 : my <= 64) && (mx > 16 || my > 16)) {
+    // real blocks, at most 32 columns on the X side and 64 on the Y side (and more than 8 on one of them): the
+    // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel)
+    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
+    if (stream && aligned && mx <= 32 && (a.same ? my <= 32 : my <= 64) && (mx > 8 || my > 8)) {
       a.npj = 1;
       a.nxs = a.nys = 1;
       a.xs[0] = GramSeg{X, ldx, 0};
       a.ys[0] = GramSeg{Y, ldy, 0};
       for (int k = 1; k < kGramSegs; ++k) a.xs[k] = a.ys[k] = GramSeg{nullptr, 0, 1 << 30};
-      return stream == 512 ? gram_stream_launch<DT, 512>(a, my, mx, d_out) : gram_stream_launch<DT, 256>(a, my, mx, d_out);
+      return gram_stream_launch<DT>(a, my, mx, d_out);
     }
   }
   // Kernel variant (see gram_kernel).  Measured at n = 10^7, m = 32 fp64: the two-chunk pipeline
@@ -790,10 +801,10 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
   a.same = 0; a.npj = npj; a.partials = c.work;
   a.nt = gram_nt(n * (mxt + myt) * es);
   if constexpr (!DType<DT>::cplx) {
-    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 256;
-    if (stream && aligned && mxt <= 32 && myt <= 64 && (mxt > 16 || myt > 16)) {
+    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
+    if (stream && aligned && mxt <= 32 && myt <= 64 && (mxt > 8 || myt > 8)) {
       a.npj = 1;
-      return stream == 512 ? gram_stream_launch<DT, 512>(a, myt, mxt, d_out) : gram_stream_launch<DT, 256>(a, myt, mxt, d_out);
+      return gram_stream_launch<DT>(a, myt, mxt, d_out);
     }
   }
   const int ROWS = 512 / (int)sizeof(R);
@@ -925,10 +936,12 @@ static int dots_impl(int64_t n, int64_t m, const void *X, int64_t ldx, const voi
   using T = typename DType<DT>::T;
   Context &c = ctx();
   constexpr int VEC = 16 / (int)sizeof(T);
-  int per = 4;                                                 // vector loads per thread
+  // vector loads per thread (a multiple of 4): at most ~2048 partials per column, so that the one wave per column
+  // of dots_finalize stays a few microseconds
+  int per = 4;
   int64_t nbx = (n + 256 * VEC * (int64_t)per - 1) / (256 * VEC * (int64_t)per);
-  while (nbx > 1 && ((size_t)nbx * m * sizeof(T) > kWorkspaceBytes / 4 || nbx > 0x7fffffff)) {
-    per *= 2;
+  while (nbx > 2048 || (nbx > 1 && (size_t)nbx * m * sizeof(T) > kWorkspaceBytes / 4)) {
+    per += 4;
     nbx = (n + 256 * VEC * (int64_t)per - 1) / (256 * VEC * (int64_t)per);
   }
   if (nbx < 1) nbx = 1;

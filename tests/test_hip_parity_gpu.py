@@ -77,6 +77,39 @@ def test_gram_vs_oracle(key, n, mx, my):
     assert np.array_equal(g, X.dot(Y))
 
 
+@pytest.mark.parametrize('key', ['d', 's'])
+@pytest.mark.parametrize('n,mx,my', [(31, 32, 32), (64, 17, 32), (30001, 24, 17), (15000, 32, 64), (12345, 20, 50),
+                                     (100003, 32, 48), (4096, 32, 33), (70001, 18, 18)])
+def test_gram_streaming_kernel_shapes(key, n, mx, my):
+    """The wave-private streaming Gram (real types, <= 32 columns on the right, <= 64 on the left): fewer rows
+    than one tile, ragged widths (clamped columns), the 64-column left window, row counts that leave a partial
+    tile; plain, self and stacked (windows made of blocks with DIFFERENT leading dimensions) requests."""
+    from raleigh_amd.algebra.hip import Vectors
+    rng = np.random.default_rng(n + 3 * mx + my)
+    x, y = rnd((mx, n), key, rng), rnd((my, n), key, rng)
+    X, Y = Vectors(x), Vectors(y)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    tol = tol_for(key, n)
+    g = X.dot(Y)
+    assert g.shape == (my, mx)
+    assert cases.rel(g, ops.gram(x64, y64)) < tol
+    assert cases.rel(X.dot(X), ops.gram(x64, x64)) < tol
+    assert np.array_equal(g, X.dot(Y))                 # fixed summation order
+    # stacked: [Y1 | Y2]^H X with Y2 a window of a wider block (another leading dimension / offset)
+    m1 = my // 2
+    wide = Vectors(n, my + 5, data_type=DT[key])
+    wide.select(my - m1, 3)
+    wide.fill(y[m1:])
+    Y1 = Vectors(y[:m1].copy())
+    rb = X.reduction_batch()
+    rb.gram([X], [Y1, wide])
+    rb.dots(X, X)
+    got, dd = rb.run()
+    assert got.shape == (my, mx)
+    assert cases.rel(got, ops.gram(x64, y64)) < tol
+    assert cases.rel(dd, ops.dots(x64, x64)) < tol
+
+
 @pytest.mark.parametrize('key', KEYS)
 def test_unaligned_leading_dimension(key):
     """A Vectors view of a C-ordered Matrix has ld = padded row length but a window of a

@@ -345,14 +345,23 @@ int main(int argc, char **argv) {
   auto report = [&](const char *name, double ms, double gb) { printf("%-58s %7.3f ms  %7.1f GB/s\n", name, ms, gb / ms * 1e3); fflush(stdout); };
   const int64_t tot = nw * m;
   report("copy_flat nt ld+st", timed([&] { hipLaunchKernelGGL((copy_flat<true, true>), dim3((tot + 255) / 256), dim3(256), 0, 0, x, y, tot); }), 2 * GB);
-  report("gram-like read x + y (64 cols), run 1 KB, 3 WG/CU, nt", timed([&] { hipLaunchKernelGGL((read_gram2<true, 1024>), dim3(cu * 3), dim3(256), 0, 0, x, y, y, ldw, nw); }), 2 * GB);
-#define SL(TB, SETS, WAVES, wpc) { char nm[160]; snprintf(nm, sizeof nm, "stream-like TB=%d sets=%d, %d-wave workgroups, %d waves/CU", TB, SETS, WAVES, wpc); \
-    report(nm, timed([&] { hipLaunchKernelGGL((read_stream_like<true, TB, SETS, WAVES>), dim3(cu * wpc / WAVES), dim3(64 * WAVES), 0, 0, x, y, y, ldw, nw); }), 2 * GB); }
-  for (int wpc : {2, 4, 8, 12, 16}) {
-    SL(256, 1, 1, wpc) SL(256, 2, 1, wpc) SL(512, 1, 1, wpc) SL(512, 2, 1, wpc) SL(1024, 1, 1, wpc)
-  }
-  for (int wpc : {4, 8, 12, 16}) {
-    SL(256, 1, 4, wpc) SL(256, 2, 4, wpc) SL(512, 1, 4, wpc) SL(512, 2, 4, wpc) SL(1024, 1, 4, wpc)
+  // does the row-wise rate depend on the leading dimension (how the 32 + 32 column streams fall onto channels / banks)?
+  // blocks re-allocated with room for the largest padding; ld = nw + pad 16-byte words
+  CK(hipFree(x)); CK(hipFree(y));
+  const int64_t maxpad = 1 << 20;
+  CK(hipMalloc(&x, (size_t)(nw + maxpad) * m * 16)); CK(hipMalloc(&y, (size_t)(nw + maxpad) * m * 16));
+  CK(hipMemset(x, 1, (size_t)(nw + maxpad) * m * 16)); CK(hipMemset(y, 2, (size_t)(nw + maxpad) * m * 16));
+  const double *xd = (const double *)x; double *yd = (double *)y;
+  Q8 qa; for (int i = 0; i < 8; ++i) qa.q[i] = 1.0 + i;
+  for (int64_t pad : {0, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576, 13, 1000, 77777}) {
+    const int64_t ldp = nw + pad;
+    char nm[160];
+    snprintf(nm, sizeof nm, "ld = n + %lld B: FLAT row-wise copy U=4 nt", (long long)pad * 16);
+    report(nm, timed([&] { hipLaunchKernelGGL((rowwise_wide<true, true, 32, 4, 1>), dim3((nw + 255) / 256), dim3(256), 0, 0, x, y, ldp, nw); }), 2 * GB);
+    snprintf(nm, sizeof nm, "ld = n + %lld B: update-like (1024 FMA/row, nt)", (long long)pad * 16);
+    report(nm, timed([&] { hipLaunchKernelGGL((rowwise_fma<0, true>), dim3((n / 2 + 255) / 256), dim3(256), 0, 0, xd, yd, 2 * ldp, n, qa, (const double *)nullptr); }), 2 * GB);
+    snprintf(nm, sizeof nm, "ld = n + %lld B: write row-wise nt", (long long)pad * 16);
+    report(nm, timed([&] { hipLaunchKernelGGL((write_rowwise<true, 32>), dim3((nw + 255) / 256), dim3(256), 0, 0, y, ldp, nw); }), GB);
   }
   return 0;
 }
