@@ -297,16 +297,33 @@ __global__ __launch_bounds__(1024) void trsv_chain_kernel(const int32_t *__restr
                                                           int l0, int l1, int sl, const int64_t *__restrict__ rowptr,
                                                           const int32_t *__restrict__ cols, const T *__restrict__ vals,
                                                           const T *__restrict__ dinv, T *W, int ldw, int ppr) {
+  constexpr int EPL = 16 / (int)sizeof(T);
+  using P = Piece<T, EPL>;
   __shared__ int s_off[kChainLevels + 1];                  // first position of every level, relative to the run's first
+  __shared__ __attribute__((aligned(16))) P s_red[16 * LPR];   // per-wave partial sums of a row spread over several waves
   const int tid = threadIdx.x;
   const int lpt = LPR * sl;
   const int64_t base = lev_off[l0];
   for (int k = tid; k <= l1 - l0; k += 1024) s_off[k] = (int)(lev_off[l0 + k] - base);
   __syncthreads();
-  const int my_row = tid / lpt, my_l = tid % lpt;          // this thread's first task of every level
-  struct Desc { int64_t pos, r, e0, e1; bool live; };
+  // Lanes per row of a level: the operator's LPR x sl, doubled while all rows of the level still fit the
+  // workgroup -- the single rows at the end of a direct factor (dense separator blocks: thousands of entries,
+  // one row per level) are walked by all 1024 threads instead of 64 lanes.  Up to 64 lanes the slices of a row
+  // are summed by shuffles; beyond, every wave of the row leaves its partial in the LDS.
+  const bool can_widen = ppr <= LPR;                       // (one trip over the pieces)
+  auto lanes_of = [&](int k) -> int {
+    int wl = lpt;
+    if (can_widen && k < l1 - l0) {
+      const int nr = s_off[k + 1] - s_off[k];
+      while (wl * 2 * nr <= 1024) wl *= 2;
+    }
+    return wl;
+  };
+  struct Desc { int64_t pos, r, e0, e1; bool live; int wl; };
   auto fetch = [&](int k) -> Desc {
     Desc d;
+    d.wl = lanes_of(k);
+    const int my_row = tid / d.wl;
     d.live = k < l1 - l0 && my_row < s_off[k + 1] - s_off[k];
     d.pos = base + (d.live ? s_off[k] + my_row : 0);
     d.r = rows[d.pos];
@@ -318,12 +335,62 @@ __global__ __launch_bounds__(1024) void trsv_chain_kernel(const int32_t *__restr
   for (int k = 0; k < l1 - l0; ++k) {
     const Desc cur = next;
     next = fetch(k + 1);                                   // in flight during this level
-    if (cur.live) trsv_row<T, LPR>(cur.r, cur.e0, cur.e1, cur.pos, my_l % LPR, my_l / LPR, sl, cols, vals, dinv, W, ldw, ppr);
-    const int64_t tasks = (int64_t)(s_off[k + 1] - s_off[k]) * lpt;
-    for (int64_t t = tid + 1024; t < tasks; t += 1024) {   // levels of more than 1024 (row, lane) tasks
-      const int64_t pos = base + s_off[k] + t / lpt;
-      const int l = (int)(t % lpt);
-      trsv_row<T, LPR>(rows[pos], rowptr[pos], rowptr[pos + 1], pos, l % LPR, l / LPR, sl, cols, vals, dinv, W, ldw, ppr);
+    const int wl = cur.wl;                                 // (workgroup-uniform)
+    if (wl <= 64) {
+      const int my_l = tid % wl;
+      if (cur.live) trsv_row<T, LPR>(cur.r, cur.e0, cur.e1, cur.pos, my_l % LPR, my_l / LPR, wl / LPR, cols, vals, dinv, W, ldw, ppr);
+      const int64_t tasks = (int64_t)(s_off[k + 1] - s_off[k]) * wl;
+      for (int64_t t = tid + 1024; t < tasks; t += 1024) {   // levels of more than 1024 (row, lane) tasks
+        const int64_t pos = base + s_off[k] + t / wl;
+        const int l = (int)(t % wl);
+        trsv_row<T, LPR>(rows[pos], rowptr[pos], rowptr[pos + 1], pos, l % LPR, l / LPR, wl / LPR, cols, vals, dinv, W, ldw, ppr);
+      }
+    } else {
+      // a row over wl / 64 whole waves: slice = lane of the row / LPR takes every (wl / LPR)-th entry
+      const int l = tid % wl, piece = l % LPR, slice = l / LPR, nsl = wl / LPR;
+      const int pc = piece < ppr ? piece : ppr - 1;
+      P acc;
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) acc.e[q] = zero_of(T{});
+      if (cur.live) {
+        for (int64_t e = cur.e0 + slice; e < cur.e1; e += 4 * (int64_t)nsl) {
+          int32_t c[4];
+          T v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t ee = e + (int64_t)u * nsl;
+            const int64_t ec = ee < cur.e1 ? ee : e;       // surplus slots repeat this lane's entry with value 0
+            c[u] = cols[ec];
+            v[u] = ee < cur.e1 ? neg_of(vals[ec]) : zero_of(T{});
+          }
+          P x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const P *>(W + (int64_t)c[u] * ldw + pc * EPL);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) fma_acc(acc.e[q], v[u], x[u].e[q]);
+        }
+      }
+      if (LPR < 64) reduce_slices<T, EPL>(acc, LPR, 64 / LPR);
+      if ((tid & 63) < LPR) s_red[(tid >> 6) * LPR + (tid & 63)] = acc;
+      __syncthreads();
+      if (cur.live && l < LPR && piece < ppr) {
+        T *wr = W + cur.r * ldw + piece * EPL;
+        P tot = *reinterpret_cast<const P *>(wr);
+        const int w0 = (tid - l) >> 6;                     // first wave of this row
+        for (int wv = 0; wv < wl / 64; ++wv) {
+          const P part = s_red[(w0 + wv) * LPR + piece];
+#pragma unroll
+          for (int q = 0; q < EPL; ++q) tot.e[q] = add_of(tot.e[q], part.e[q]);
+        }
+        if (dinv) {
+          const T d = dinv[cur.pos];
+#pragma unroll
+          for (int q = 0; q < EPL; ++q) tot.e[q] = mul_of(tot.e[q], d);
+        }
+        *reinterpret_cast<P *>(wr) = tot;
+      }
     }
     __syncthreads();
   }

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for m in 32 24; do timeout -k 10 120 python tools/gram_series.py $m || exit 1; done
-echo "== waves 8"; RLH_GRAM_STREAM_WAVES=8 timeout -k 10 120 python tools/gram_series.py 32 || exit 1
-echo "== waves 3"; RLH_GRAM_STREAM_WAVES=3 timeout -k 10 120 python tools/gram_series.py 32 || exit 1
+timeout -k 10 900 python -m pytest tests/test_configs_gpu.py tests/test_hip_parity_gpu.py -x -q -k "triang or ilu or chain or shift or sptrsv or config" 2>&1 | tail -3 || exit 1
+timeout -k 10 300 python tools/small_solve.py 2>&1 | tail -5
+timeout -k 10 300 python tools/ilu_bench.py fe | tail -3
+timeout -k 10 300 python tools/ilu_bench.py lap100 | tail -3
