@@ -491,8 +491,14 @@ static int gram_nt(int64_t bytes) {
 // NYC = staged Y columns: 32, 64, or 0 for a self-Gram (A and B fragments both from the X image, tiles on and
 // above the diagonal only).  Windows may be concatenations of blocks (GramArgs segments).  Results: one partial
 // per wave, combined by gram_finalize in a fixed order.
+// Waves per workgroup: the waves are independent (no barrier), but they are launched as ONE workgroup per CU --
+// its LDS request is padded beyond half of the CU's LDS so that no two fit -- because the dispatcher does not
+// spread one-wave workgroups evenly: right after a kernel with a large grid (dots, copy) some CUs received five
+// waves and others three, and the launch took as long as its fullest CU (0.90-0.95 ms instead of 0.76 ms).
+constexpr int gram_stream_waves(int ncol) { return ncol <= 16 ? 16 : (ncol <= 32 ? 8 : 4); }
+
 template <typename R, int TB, int NYC, int NXC, bool NT>
-__global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
+__global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream_kernel(GramArgs a) {
   using M = Mfma16<R>;
   using acc_t = typename M::acc_t;
   constexpr bool SELF = NYC == 0;
@@ -506,9 +512,11 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
   constexpr int SW = NP / 16;
   constexpr int PJ = NXC / 16, PI = SELF ? PJ : NYC / 16;
   static_assert(NP >= 16 && NP <= 64 && 64 % NP == 0 && NCOL % CPL == 0, "tile shape");
-  __shared__ __attribute__((aligned(16))) char lds[NCOL * TB];
+  constexpr int WPG = gram_stream_waves(NYC + NXC);
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  char *lds = lds_all + (threadIdx.x >> 6) * (NCOL * TB);   // this wave's private image
   typedef R vec_t __attribute__((ext_vector_type(RPU)));
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int p = lane % NP, cl = lane / NP;
 
   // this lane's piece of staged column q * CPL + cl at row 0 (columns past a window repeat its last one: they
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
 
   // Tile j of this wave is t0 + j G; loads past its last tile re-read that tile (an L2 hit) and are dropped, so
   // the loop body is straight-line code and the compiler waits with counted vmcnt for the older set only.
-  const int64_t nfull = a.n / ROWS, G = gridDim.x, t0 = blockIdx.x;
+  const int64_t nfull = a.n / ROWS, G = (int64_t)gridDim.x * WPG, t0 = (int64_t)blockIdx.x * WPG + (threadIdx.x >> 6);
   const int64_t count = t0 < nfull ? (nfull - t0 + G - 1) / G : 0;
   auto tile_of = [&](int64_t j) -> int64_t { return t0 + (j < count ? j : count - 1) * G; };
   if (count > 0) {
@@ -625,13 +633,13 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (nfull * ROWS < a.n && nfull % G == blockIdx.x) {
+  if (nfull * ROWS < a.n && nfull % G == t0) {
     load_tail(nfull, regsA);
     store_tile(regsA);
     __builtin_amdgcn_wave_barrier();
     compute();
   }
-  R *out = reinterpret_cast<R *>(a.partials) + blockIdx.x;
+  R *out = reinterpret_cast<R *>(a.partials) + t0;
 #pragma unroll
   for (int i = 0; i < PI; ++i)
 #pragma unroll
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(64) void gram_stream_kernel(GramArgs a) {
       for (int r = 0; r < 4; ++r) {
         if (SELF && i > j) continue;
         const int ii = i * 16 + M::out_row(lane, r), jj = j * 16 + (lane & 15);
-        out[(int64_t)(ii * NXC + jj) * gridDim.x] = acc[i][j][r];
+        out[(int64_t)(ii * NXC + jj) * G] = acc[i][j][r];
       }
 }
 
@@ -655,27 +663,33 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   const bool self = a.same;
   const int nxc = mx <= 16 ? 16 : 32;
   const int nyc = self ? 0 : (my <= 16 ? 16 : (my <= 32 ? 32 : 64));
-  const int lds_per_wave = (nyc + nxc) * TB;
-  // One wave per SIMD where a tile is 16 KB (64 staged columns) or more: with two register sets in flight per wave
-  // more waves only widen the window of rows the chip works on at once (measured 6.3 TB/s at 4 waves per CU, 6.2 at
-  // 8, 4.8 at 2); narrower tiles take proportionally more waves.  RLH_GRAM_STREAM_WAVES: tunable.
-  int per_cu = 65536 / lds_per_wave;             // 64 staged columns: 4, 32: 8, 16: 16 (two sets of a tile each in flight)
-  per_cu = per_cu < 4 ? 4 : (per_cu + 1) & ~1;
-  const char *e = getenv("RLH_GRAM_STREAM_WAVES");
-  if (e && *e && atoi(e) > 0) per_cu = atoi(e);
-  if (per_cu > 160 * 1024 / lds_per_wave) per_cu = 160 * 1024 / lds_per_wave;
-  int64_t nbx = (int64_t)c.num_cu * per_cu;
+  // One workgroup per CU of 4 waves (one per SIMD) where a tile is 12 KB or more, 8 / 16 waves for narrower
+  // tiles: with two register sets in flight per wave more waves only widen the window of rows the chip works on
+  // at once (measured 6.3-6.7 TB/s at 4 waves per CU, 6.2 at 8, 4.8 at 2).
+  const int wpg = gram_stream_waves(nyc + nxc);
+  size_t lds = (size_t)wpg * (nyc + nxc) * TB;
+  if (lds < 84 * 1024) lds = 84 * 1024;          // more than half of the CU's 160 KB: one workgroup per CU
   const int64_t ntiles = (a.n + ROWS - 1) / ROWS;
-  if (nbx > ntiles) nbx = ntiles;
+  int64_t nbx = c.num_cu;
+  if (nbx * wpg > ntiles) nbx = (ntiles + wpg - 1) / wpg;
   if (nbx < 1) nbx = 1;
+  const int64_t nparts = nbx * wpg;
   const int VY = self ? nxc : nyc;
-  RLH_REQUIRE((size_t)nbx * VY * nxc * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
+  RLH_REQUIRE((size_t)nparts * VY * nxc * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
+#define RLH_GS1(NYC_, NXC_, NT_)                                                                                       \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<R, TB, NYC_, NXC_, NT_>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, NT_>), dim3((unsigned)nbx),                              \
+                       dim3(64 * gram_stream_waves(NYC_ + NXC_)), lds, c.stream, a);                                  \
+  } while (0)
 #define RLH_GS(NYC_, NXC_)                                                                                             \
   do {                                                                                                                 \
-    if (a.nt & 1)                                                                                                      \
-      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, true>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a);  \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, false>), dim3((unsigned)nbx), dim3(64), 0, c.stream, a); \
+    if (a.nt & 1) RLH_GS1(NYC_, NXC_, true); else RLH_GS1(NYC_, NXC_, false);                                          \
   } while (0)
   if (nxc == 16) {
     if (nyc == 0) RLH_GS(0, 16); else if (nyc == 16) RLH_GS(16, 16); else if (nyc == 32) RLH_GS(32, 16); else RLH_GS(64, 16);
@@ -683,9 +697,10 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
     if (nyc == 0) RLH_GS(0, 32); else if (nyc == 16) RLH_GS(16, 32); else if (nyc == 32) RLH_GS(32, 32); else RLH_GS(64, 32);
   }
 #undef RLH_GS
+#undef RLH_GS1
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
-  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nbx, 1, VY, nxc,
+  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nparts, 1, VY, nxc,
                      (int)my, (int)mx, d_out, a.same);
   RLH_HIP(hipGetLastError());
   return 0;

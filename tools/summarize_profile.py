@@ -40,7 +40,7 @@ for k in sorted(acc['fetch']):
         k[:58], len(rd), sum(rd) / len(rd), max(rd), sum(wr) / len(wr)))
     out.setdefault('traffic_gb', {})[k] = {'read_avg': sum(rd) / len(rd), 'read_max': max(rd),
                                            'write_avg': sum(wr) / len(wr)}
-g = [k for k in acc['fetch'] if k.startswith('gram_kernel')]
+g = [k for k in acc['fetch'] if k.startswith('gram_') and 'finalize' not in k]
 if g:
     # the headline's two-operand X.dot(Y) launches: the Gram instance launched most often (the self-Gram and
     # the stacked multi-block Grams of the fused leg run under other template instances)
