@@ -608,7 +608,20 @@ __global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream
   const int64_t nfull = a.n / ROWS, G = (int64_t)gridDim.x * WPG, t0 = (int64_t)blockIdx.x * WPG + (threadIdx.x >> 6);
   const int64_t count = t0 < nfull ? (nfull - t0 + G - 1) / G : 0;
   auto tile_of = [&](int64_t j) -> int64_t { return t0 + (j < count ? j : count - 1) * G; };
-  if (count > 0) {
+  if constexpr (NCOL >= 128) {
+    // (128 staged columns: one register set of 32 pieces -- two would spill; a tile is 32 KB, so one tile per wave in
+    // flight during its compute phase is as many bytes per CU as two tiles of the 64-column shapes)
+    if (count > 0) {
+      load_tile(tile_of(0), regsA);
+      for (int64_t i = 0; i < count; ++i) {
+        store_tile(regsA);
+        __builtin_amdgcn_wave_barrier();
+        load_tile(tile_of(i + 1), regsA);
+        compute();
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else if (count > 0) {
     load_tile(tile_of(0), regsA);
     __builtin_amdgcn_sched_barrier(0);
     load_tile(tile_of(1), regsB);
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream
       }
 }
 
-// my <= 64 (32 for a self-Gram), mx <= 32, every segment 16-byte aligned; a.xs / a.ys / a.nxs / a.nys describe the
+// my <= 64, mx <= 64, every segment 16-byte aligned; a.xs / a.ys / a.nxs / a.nys describe the
 // windows, a.same a self-Gram of one block.
 template <int DT>
 static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) {
@@ -661,8 +674,8 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   constexpr int TB = 256;
   constexpr int ROWS = TB / (int)sizeof(R);
   const bool self = a.same;
-  const int nxc = mx <= 16 ? 16 : 32;
-  const int nyc = self ? 0 : (my <= 16 ? 16 : (my <= 32 ? 32 : 64));
+  const int nxc = mx <= 16 ? 16 : (mx <= 32 ? 32 : 64);
+  const int nyc = self ? 0 : (my <= 16 && nxc < 64 ? 16 : (my <= 32 && nxc < 64 ? 32 : 64));
   // One workgroup per CU of 4 waves (one per SIMD) where a tile is 12 KB or more, 8 / 16 waves for narrower
   // tiles: with two register sets in flight per wave more waves only widen the window of rows the chip works on
   // at once (measured 6.3-6.7 TB/s at 4 waves per CU, 6.2 at 8, 4.8 at 2).
@@ -693,8 +706,10 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   } while (0)
   if (nxc == 16) {
     if (nyc == 0) RLH_GS(0, 16); else if (nyc == 16) RLH_GS(16, 16); else if (nyc == 32) RLH_GS(32, 16); else RLH_GS(64, 16);
-  } else {
+  } else if (nxc == 32) {
     if (nyc == 0) RLH_GS(0, 32); else if (nyc == 16) RLH_GS(16, 32); else if (nyc == 32) RLH_GS(32, 32); else RLH_GS(64, 32);
+  } else {
+    if (nyc == 0) RLH_GS(0, 64); else RLH_GS(64, 64);
   }
 #undef RLH_GS
 #undef RLH_GS1
@@ -726,7 +741,7 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
     // real blocks, at most 32 columns on the X side and 64 on the Y side (and more than 8 on one of them): the
     // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel)
     static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    if (stream && aligned && mx <= 32 && (a.same ? my <= 32 : my <= 64) && (mx > 8 || my > 8)) {
+    if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8)) {
       a.npj = 1;
       a.nxs = a.nys = 1;
       a.xs[0] = GramSeg{X, ldx, 0};
@@ -817,7 +832,7 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
   a.nt = gram_nt(n * (mxt + myt) * es);
   if constexpr (!DType<DT>::cplx) {
     static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    if (stream && aligned && mxt <= 32 && myt <= 64 && (mxt > 8 || myt > 8)) {
+    if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8)) {
       a.npj = 1;
       return gram_stream_launch<DT>(a, myt, mxt, d_out);
     }

@@ -79,7 +79,8 @@ def test_gram_vs_oracle(key, n, mx, my):
 
 @pytest.mark.parametrize('key', ['d', 's'])
 @pytest.mark.parametrize('n,mx,my', [(31, 32, 32), (64, 17, 32), (30001, 24, 17), (15000, 32, 64), (12345, 20, 50),
-                                     (100003, 32, 48), (4096, 32, 33), (70001, 18, 18)])
+                                     (100003, 32, 48), (4096, 32, 33), (70001, 18, 18), (20001, 64, 64), (9000, 40, 20),
+                                     (33333, 50, 64), (5000, 9, 3), (777, 12, 12)])
 def test_gram_streaming_kernel_shapes(key, n, mx, my):
     """The wave-private streaming Gram (real types, <= 32 columns on the right, <= 64 on the left): fewer rows
     than one tile, ragged widths (clamped columns), the 64-column left window, row counts that leave a partial
