@@ -739,9 +739,11 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
   if constexpr (!DType<DT>::cplx) {
     // real blocks, at most 32 columns on the X side and 64 on the Y side (and more than 8 on one of them): the
-    // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel)
-    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8)) {
+    // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel; =2: the streaming kernel whatever the size)
+    const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
+    // (blocks that fit the Infinity Cache stay with the workgroup kernel: the streaming kernel writes one partial per
+    // wave -- 8 MB at 32 x 32 -- and measured 44 vs 39 us at n = 262144, 21 vs 14 us at n = 27000)
+    if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8) && (a.nt || stream > 1)) {
       a.npj = 1;
       a.nxs = a.nys = 1;
       a.xs[0] = GramSeg{X, ldx, 0};
@@ -831,8 +833,8 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
   a.same = 0; a.npj = npj; a.partials = c.work;
   a.nt = gram_nt(n * (mxt + myt) * es);
   if constexpr (!DType<DT>::cplx) {
-    static const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8)) {
+    const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
+    if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8) && (a.nt || stream > 1)) {
       a.npj = 1;
       return gram_stream_launch<DT>(a, myt, mxt, d_out);
     }

@@ -81,11 +81,12 @@ def test_gram_vs_oracle(key, n, mx, my):
 @pytest.mark.parametrize('n,mx,my', [(31, 32, 32), (64, 17, 32), (30001, 24, 17), (15000, 32, 64), (12345, 20, 50),
                                      (100003, 32, 48), (4096, 32, 33), (70001, 18, 18), (20001, 64, 64), (9000, 40, 20),
                                      (33333, 50, 64), (5000, 9, 3), (777, 12, 12)])
-def test_gram_streaming_kernel_shapes(key, n, mx, my):
+def test_gram_streaming_kernel_shapes(key, n, mx, my, monkeypatch):
     """The wave-private streaming Gram (real types, <= 32 columns on the right, <= 64 on the left): fewer rows
     than one tile, ragged widths (clamped columns), the 64-column left window, row counts that leave a partial
     tile; plain, self and stacked (windows made of blocks with DIFFERENT leading dimensions) requests."""
     from raleigh_amd.algebra.hip import Vectors
+    monkeypatch.setenv('RLH_GRAM_STREAM', '2')         # (by default only blocks beyond the Infinity Cache take this kernel)
     rng = np.random.default_rng(n + 3 * mx + my)
     x, y = rnd((mx, n), key, rng), rnd((my, n), key, rng)
     X, Y = Vectors(x), Vectors(y)
