@@ -1098,12 +1098,21 @@ def _pivoted_cholesky(G, k, eps):
         U[:k, k:] = U[:k, k:][:, P]
         U[k:, k:] = Us
         ind[k:] = [ind[k + int(q)] for q in P]
-    # condition control: the reciprocal condition number of the kept Gram block must exceed eps
-    while kept > 0:
-        sv = np.linalg.svd(U[:k + kept, :k + kept], compute_uv=False)
-        if (sv[-1] / sv[0]) ** 2 > eps:
-            break
-        kept -= 1
+    # condition control: the reciprocal condition number of the kept Gram block must exceed eps.  The condition
+    # number of a leading block grows with its size (interlacing), so the largest admissible `kept` is found by
+    # bisection: one SVD in the common case, log2(kept) of them instead of one per dropped column otherwise.
+    def well_conditioned(q):
+        sv = np.linalg.svd(U[:k + q, :k + q], compute_uv=False)
+        return (sv[-1] / sv[0]) ** 2 > eps
+    if kept > 0 and not well_conditioned(kept):
+        lo, hi = 0, kept - 1                    # the answer lies in [lo, hi]; kept = 0 needs no check
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if well_conditioned(mid):
+                lo = mid
+            else:
+                hi = mid - 1
+        kept = lo
     U[k + kept:, :] = 0
     U[:, k + kept:] = 0
     return U, ind, r - kept

@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
                                                            const T *__restrict__ Q, int ldq, int64_t n, int k,
                                                            int m, T *__restrict__ Out2, int64_t ldo2, int msplit) {
   using V = RowVec<T, RV>;
-  const int j0 = blockIdx.y * JT;
+  // workgroup index = row block x panels + panel: the panels of one row block (the two result blocks of
+  // rlh_block_update2x2 take two) are dispatched side by side, so the second one finds the rows of X that the first
+  // just read in the L2 / Infinity Cache instead of streaming both sources from HBM again
+  const int npanels = (m + JT - 1) / JT;
+  const int j0 = (int)(blockIdx.x % npanels) * JT;
+  const int64_t rowblock = blockIdx.x / npanels;
   const int jv = (m - j0) < JT ? (m - j0) : JT;      // valid output columns of this panel
   const T *__restrict__ Qp = Q + j0;
   // output column j of the panel: columns < msplit live in Out, the others in Out2 (two result
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void block_update_kernel(const T *__restrict__
   };
   // one row group per lane, no loop: the grid covers every row (launch_update_rv), so the resident workgroups are a
   // compact window sweeping the blocks front to back
-  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * RV, once = 0; once < 1; ++once) {
+  for (int64_t row = (rowblock * 256 + threadIdx.x) * RV, once = 0; once < 1; ++once) {
     // every row group of the wave is complete (wave-uniform): straight-line loads, the columns of X
     // in a two-stage register pipeline -- the loads of the next kUnrollK columns are in flight during
     // the FMAs of the current ones (with one predicate per load the compiler put every load behind a
@@ -220,8 +225,9 @@ static int launch_update_rv(const T *X, int64_t ldx, T *Out, int64_t ldo, const 
   Context &c = ctx();
   int64_t nbx = ((n + RV - 1) / RV + 255) / 256;
   // one row group per lane and no loop (see row_blocks below)
-  RLH_REQUIRE(nbx <= 0x7fffffff, "rlh_block_update: %lld rows exceed the grid", (long long)n);
-  dim3 grid((unsigned)nbx, (unsigned)((m + JT - 1) / JT));
+  const int64_t npanels = (m + JT - 1) / JT;
+  RLH_REQUIRE(nbx * npanels <= 0x7fffffff, "rlh_block_update: %lld rows exceed the grid", (long long)n);
+  dim3 grid((unsigned)(nbx * npanels));
   const int nt = update_nt((int64_t)n * (k + k2 + (beta ? 2 : 1) * m) * (int64_t)sizeof(T));
 #define RLH_UPD(BETA_, NT_)                                                                                              \
   hipLaunchKernelGGL((block_update_kernel<T, JT, BETA_, RV, NT_>), grid, dim3(256), 0, c.stream, X, ldx, X2, ldx2, k2, kpad, \
@@ -397,7 +403,8 @@ static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *
       return launch_update_mfma<T>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad, Out2, ldo2, msplit);
   }
   // 16-byte row groups where RV * JT accumulators of T fit (<= 128 registers) and every block is
-  // 16-byte aligned (RLH_UPDATE_RV=0: one row per lane, tunable)
+  // 16-byte aligned (RLH_UPDATE_RV=0: one row per lane, tunable; 2 x 64 fp64 accumulators per lane spill: 6.2 ms
+  // against 2.8 ms with one row per lane for the 64-column panels)
   constexpr int RVMAX = 16 / (int)sizeof(T);
   if constexpr (RVMAX > 1 && RVMAX * JT * sizeof(T) <= 512) {
     static const int rv = env_flag("RLH_UPDATE_RV", 1);
@@ -416,7 +423,9 @@ static int block_update_impl(int64_t n, int64_t k, const void *X_, int64_t ldx, 
   const T *X = (const T *)X_;
   T *Out = (T *)Out_;
   const T *q = (const T *)q_;
-  const int JT = (m <= 8) ? 8 : ((m <= 16 || JTMAX == 16) ? 16 : 32);
+  // (fp64 results of more than 32 columns: panels of 64 with one row per lane -- two panels of 32 read every source
+  // twice: 3.0 -> 2.0 ms for m = k = 64 at n = 215^3)
+  const int JT = (m <= 8) ? 8 : ((m <= 16 || JTMAX == 16) ? 16 : ((DT == RLH_D && m > 32) ? 64 : 32));
   const int64_t mpad = (m + JT - 1) / JT * JT;
   // rows of Q per launch so that the padded coefficient block fits one ring slot
   int64_t kmax = (int64_t)(kRingSlotBytes / (mpad * sizeof(T))) / kUnrollK * kUnrollK;
@@ -444,6 +453,11 @@ static int block_update_impl(int64_t n, int64_t k, const void *X_, int64_t ldx, 
       rc = launch_update<T, 8>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk, (int)m, b);
     } else if (JT == 16) {
       rc = launch_update<T, 16>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk, (int)m, b);
+    } else if (JT == 64) {
+      if constexpr (DT == RLH_D)
+        rc = launch_update<T, 64>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk, (int)m, b);
+      else
+        rc = 1;
     } else {
       rc = launch_update<T, (JTMAX == 32 ? 32 : 16)>(X + k0 * ldx, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)kk,
                                                      (int)m, b);
@@ -463,7 +477,7 @@ static int block_update2_impl(int64_t n, int64_t k1, const void *X1_, int64_t ld
   using T = typename DType<DT>::T;
   constexpr int JTMAX = DType<DT>::cplx ? 16 : 32;
   const T *q1 = (const T *)q1_, *q2 = (const T *)q2_;
-  const int JT = (m <= 8) ? 8 : ((m <= 16 || JTMAX == 16) ? 16 : 32);
+  const int JT = (m <= 8) ? 8 : ((m <= 16 || JTMAX == 16) ? 16 : ((DT == RLH_D && m > 32) ? 64 : 32));
   const int64_t mpad = (m + JT - 1) / JT * JT;
   const int64_t kp1 = (k1 + kUnrollK - 1) / kUnrollK * kUnrollK, kp2 = (k2 + kUnrollK - 1) / kUnrollK * kUnrollK;
   const size_t bytes = (size_t)((kp1 + kp2) * mpad) * sizeof(T);
@@ -488,7 +502,13 @@ static int block_update2_impl(int64_t n, int64_t k1, const void *X1_, int64_t ld
   else if (JT == 16)
     rc = launch_update<T, 16>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m, beta, X2, ldx2,
                               (int)k2, (int)kp1, OutB, ldob, (int)ma);
-  else
+  else if (JT == 64) {
+    if constexpr (DT == RLH_D)
+      rc = launch_update<T, 64>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m, beta, X2, ldx2,
+                                (int)k2, (int)kp1, OutB, ldob, (int)ma);
+    else
+      rc = 1;
+  } else
     rc = launch_update<T, (JTMAX == 32 ? 32 : 16)>(X1, ldx1, Out, ldo, (const T *)d, (int)mpad, n, (int)k1, (int)m,
                                                    beta, X2, ldx2, (int)k2, (int)kp1, OutB, ldob, (int)ma);
   if (rc) return rc;
