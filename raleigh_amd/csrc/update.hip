@@ -379,14 +379,202 @@ static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, cons
   return 0;
 }
 
-// (A matrix-core version of the REAL update -- X fragments loaded in MFMA layout, 16 lanes x 16 bytes per column --
-// was measured and dropped: 1.16-1.30 ms against 1.02 ms for the multiply at n = 215^3, m = k = 32 fp64.  The real
-// update is bound by its 64 interleaved column streams, not by arithmetic: the same loads and stores with no
-// arithmetic at all run at the same rate, tools/stream_probe.hip, and 256-byte runs stream slower than 1-KB runs.)
+// ---------------------------------------------------------------- real block update on the matrix cores
+// Out = beta Out + X Q (+ X2 Q2) for float / double blocks, rows of X on the MFMA's N side: D^T (16 result columns x 16
+// rows) = Q^T (16 x 4) X^T (4 x 16), so lane (kk, rl) loads ITS 16 bytes -- rows V rl .. V rl + V - 1, V = 16 / sizeof(R),
+// of column 4 s + kk -- straight from global memory as the B operand of k-step s, and stores 16 bytes of rows
+// V rl .. of result column 16 t + out_row(lane, g): one wave instruction moves 4 columns x 256 contiguous bytes,
+// which streams as fast as 1-KB runs of one column (5.8 TB/s for the bare 32 + 32 column copy of this shape,
+// tools/stream_probe.hip section 14).  A wave walks TPW consecutive tiles of 16 V rows with the X fragments of the
+// NEXT tile in flight during the MFMAs and stores of the current one (two register sets); the coefficients sit in
+// the LDS in fragment order [column tile][k-step][lane], re-laid-out once per workgroup (4 waves x TPW tiles, so that
+// this costs a few percent of the traffic), one ds_read per V MFMAs.  No run-time switch touches a load or store.
+// What it replaces: the SGPR-fed VALU kernel above issues 2 k m v_fma per row; for results of more than 32 columns
+// its accumulators no longer fit beside 16-byte accesses, it falls back to 8 bytes per lane and is bound by its
+// arithmetic (2.8 ms for the driver's 64 -> 64 column update at n = 215^3, where the stream needs 1.75 ms).
+// (A first matrix-core version -- one tile per wave, coefficients re-staged by every 128 rows -- measured
+// 1.16-1.30 ms against 1.02 ms for m = k = 32 and was dropped; this one amortises both.)
+constexpr int kUpdTilesPerWave = 8;
+template <typename R, int KS, bool BETA, bool NT>
+__global__ __launch_bounds__(256) void block_update_stream_kernel(const R *__restrict__ X, int64_t ldx, int k1, int ks1,
+                                                                  const R *X2, int64_t ldx2, int k2, int ks2,   // (X2 may BE Out:
+                                                                  R *Out, int64_t ldo, R *Out2,                  //  the folded add)
+                                                                  int64_t ldo2, int msplit, const R *__restrict__ Q, int ldq,
+                                                                  int64_t n, int m) {
+  using M = Mfma16x4<R>;
+  using acc_t = typename M::acc_t;
+  constexpr int V = 16 / (int)sizeof(R);
+  constexpr int TR = 16 * V;                               // rows of one tile
+  typedef R vec_t __attribute__((ext_vector_type(V)));
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  R *qf = reinterpret_cast<R *>(lds_raw);                 // [column tile][k-step][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nks = ks1 + ks2, ntile = (m + 15) / 16;
+  for (int idx = tid; idx < ntile * nks * 64; idx += 256) {
+    const int l = idx & 63, s = (idx >> 6) % nks, t = (idx >> 6) / nks;
+    const int col = 16 * t + (l & 15);
+    qf[idx] = col < m ? Q[(int64_t)(4 * s + (l >> 4)) * ldq + col] : (R)0;   // (rows past k1 / k2 are zero padding)
+  }
+  __syncthreads();
+  const int kk = lane >> 4, rl = lane & 15;
+  const int64_t ntiles = (n + TR - 1) / TR;
+  // the four waves of a workgroup take CONSECUTIVE tiles in every step (wave w: tiles base + 4 i + w), so a step of
+  // the workgroup touches 4 x 256 contiguous bytes of every column at about the same time
+  const int64_t tile0 = (int64_t)blockIdx.x * 4 * kUpdTilesPerWave + (tid >> 6);
+  if (tile0 >= ntiles) return;
+  const int64_t wg_end = ((int64_t)blockIdx.x + 1) * 4 * kUpdTilesPerWave;
+  const int64_t tile1 = wg_end < ntiles ? wg_end : ntiles;
+  // this lane's column of every k-step (columns inside the zero padding of Q repeat the last one)
+  const R *xcol[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const bool first = s < ks1;
+    int c = first ? 4 * s + kk : 4 * (s - ks1) + kk;
+    const int kmax = first ? k1 : k2;
+    c = c < kmax ? c : kmax - 1;
+    c = c < 0 ? 0 : c;
+    xcol[s] = (first ? X + (int64_t)c * ldx : X2 + (int64_t)c * ldx2) + V * rl;
+  }
+  vec_t xa[KS], xb[KS];
+  auto load_x = [&](int64_t tile, vec_t (&xf)[KS]) {
+    const int64_t r0 = tile * TR;
+    if (r0 + TR <= n) {                                   // wave-uniform
+      // (unconditional: k-steps past the last re-read a valid column -- an L1 hit -- because a branch around a
+      // load costs the counted vmcnt waits of the whole pipeline)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if constexpr (NT) xf[s] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(xcol[s] + r0));
+        else xf[s] = *reinterpret_cast<const vec_t *>(xcol[s] + r0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        if (s < nks) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const int64_t r = r0 + V * rl + v < n ? r0 + v : n - 1 - V * rl;   // rows past the end repeat the last (never stored)
+            xf[s][v] = xcol[s][r];
+          }
+        }
+    }
+  };
+  auto process = [&](int64_t tile, const vec_t (&xf)[KS]) {
+    const int64_t r0 = tile * TR + V * rl;
+    const bool full = (tile + 1) * TR <= n;                // wave-uniform
+    for (int t = 0; t < ntile; ++t) {
+      acc_t d[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) d[v] = acc_t{(R)0, (R)0, (R)0, (R)0};
+      if (BETA) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = 16 * t + M::out_row(lane, g);
+          if (j < m) {
+            const R *o = (j < msplit ? Out + (int64_t)j * ldo : Out2 + (int64_t)(j - msplit) * ldo2) + r0;
+            if (full) {
+              vec_t ov;
+              if constexpr (NT) ov = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(o));
+              else ov = *reinterpret_cast<const vec_t *>(o);
+#pragma unroll
+              for (int v = 0; v < V; ++v) d[v][g] = ov[v];
+            } else {
+#pragma unroll
+              for (int v = 0; v < V; ++v)
+                if (r0 + v < n) d[v][g] = o[v];
+            }
+          }
+        }
+      }
+      const R *qt = qf + (int64_t)t * nks * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s < nks) {
+          const R q = qt[s * 64];
+#pragma unroll
+          for (int v = 0; v < V; ++v) d[v] = M::run(q, xf[s][v], d[v]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = 16 * t + M::out_row(lane, g);
+        if (j < m) {
+          R *o = (j < msplit ? Out + (int64_t)j * ldo : Out2 + (int64_t)(j - msplit) * ldo2) + r0;
+          if (full) {
+            vec_t ov;
+#pragma unroll
+            for (int v = 0; v < V; ++v) ov[v] = d[v][g];
+            if constexpr (NT) __builtin_nontemporal_store(ov, reinterpret_cast<vec_t *>(o));
+            else *reinterpret_cast<vec_t *>(o) = ov;
+          } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+              if (r0 + v < n) o[v] = d[v][g];
+          }
+        }
+      }
+    }
+  };
+  // two register sets: the loads of tile i + 1 are outstanding while tile i is multiplied and stored
+  load_x(tile0, xa);
+  int64_t tile = tile0;
+  for (; tile + 4 < tile1; tile += 8) {
+    load_x(tile + 4, xb);
+    process(tile, xa);
+    if (tile + 8 < tile1) load_x(tile + 8, xa);
+    process(tile + 4, xb);
+  }
+  if (tile < tile1) process(tile, xa);
+}
+
+template <typename R, int KS>
+static int launch_update_stream_ks(const R *X, int64_t ldx, R *Out, int64_t ldo, const R *Qd, int ldq, int64_t n, int k,
+                                   int m, int beta, const R *X2, int64_t ldx2, int k2, int ks1, int ks2, R *Out2,
+                                   int64_t ldo2, int msplit, size_t lds) {
+  Context &c = ctx();
+  const int nt = update_nt((int64_t)n * (k + k2 + (beta ? 2 : 1) * m) * (int64_t)sizeof(R));
+  constexpr int TR = 16 * (16 / (int)sizeof(R));
+  const int64_t rows_per_wg = (int64_t)4 * kUpdTilesPerWave * TR;
+  const int64_t nb = (n + rows_per_wg - 1) / rows_per_wg;
+  RLH_REQUIRE(nb >= 1 && nb <= 0x7fffffff, "rlh_block_update: %lld rows exceed the grid", (long long)n);
+  if (X2 == nullptr || k2 <= 0) { X2 = X; ldx2 = ldx; }
+#define RLH_UPDS(BETA_, NT_)                                                                                              \
+  hipLaunchKernelGGL((block_update_stream_kernel<R, KS, BETA_, NT_>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, \
+                     k, ks1, X2, ldx2, k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m)
+  if (nt) { if (beta) RLH_UPDS(true, true); else RLH_UPDS(false, true); }
+  else { if (beta) RLH_UPDS(true, false); else RLH_UPDS(false, false); }
+#undef RLH_UPDS
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename R>
+static int launch_update_stream(const R *X, int64_t ldx, R *Out, int64_t ldo, const R *Qd, int ldq, int64_t n, int k, int m,
+                                int beta, const R *X2, int64_t ldx2, int k2, int kpad, R *Out2, int64_t ldo2, int msplit) {
+  const bool two = X2 && k2 > 0;
+  const int ks1 = two ? kpad / 4 : (k + 3) / 4, ks2 = two ? (k2 + 3) / 4 : 0;
+  const size_t lds = (size_t)((m + 15) / 16) * (ks1 + ks2) * 64 * sizeof(R);
+  if (!two) k2 = 0;
+  if (ks1 + ks2 <= 8)
+    return launch_update_stream_ks<R, 8>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, ks1, ks2, Out2, ldo2, msplit, lds);
+  if (ks1 + ks2 <= 16)
+    return launch_update_stream_ks<R, 16>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, ks1, ks2, Out2, ldo2, msplit, lds);
+  return launch_update_stream_ks<R, 32>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, ks1, ks2, Out2, ldo2, msplit, lds);
+}
 
 template <typename T> struct IsComplex { static constexpr bool value = false; };
 template <> struct IsComplex<c32> { static constexpr bool value = true; };
 template <> struct IsComplex<c64> { static constexpr bool value = true; };
+
+// can the streaming matrix-core kernel take this real update?  (RLH_UPDATE_STREAM=0: the VALU kernel; tunable)
+template <typename T>
+static bool update_stream_ok(const T *X, int64_t ldx, const T *Out, int64_t ldo, const T *Out2, int64_t ldo2, const T *X2,
+                             int64_t ldx2, int k, int k2, int kpad, int m) {
+  const int ks = (X2 && k2 > 0 ? kpad / 4 + (k2 + 3) / 4 : (k + 3) / 4);
+  const size_t lds = (size_t)((m + 15) / 16) * ks * 64 * sizeof(T);
+  return env_flag("RLH_UPDATE_STREAM", 1) && k + k2 >= 8 && m >= 8 && ks <= kMfmaUpdKS && lds <= 64 * 1024 &&
+         aligned16(X, ldx, sizeof(T)) && aligned16(Out, ldo, sizeof(T)) && aligned16(Out2, ldo2, sizeof(T)) &&
+         (!X2 || k2 == 0 || aligned16(X2, ldx2, sizeof(T)));
+}
 
 template <typename T, int JT>
 static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
@@ -401,6 +589,12 @@ static int launch_update(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *
     if (env_flag("RLH_UPDATE_MFMA", 1) && k + k2 >= 16 && m >= 16 && ks <= kMfmaUpdKS && lds <= 160 * 1024 &&
         aligned16(X, ldx, sizeof(T)) && (!X2 || k2 == 0 || aligned16(X2, ldx2, sizeof(T))))
       return launch_update_mfma<T>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad, Out2, ldo2, msplit);
+  }
+  if constexpr (!IsComplex<T>::value) {
+    // the matrix cores for real blocks: results of at least 8 columns from at least 8, coefficients within 64 KB of
+    // LDS, k-steps within the register sets
+    if (update_stream_ok<T>(X, ldx, Out, ldo, Out2, ldo2, X2, ldx2, k, k2, kpad, m))
+      return launch_update_stream<T>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, kpad, Out2, ldo2, msplit);
   }
   // 16-byte row groups where RV * JT accumulators of T fit (<= 128 registers) and every block is
   // 16-byte aligned (RLH_UPDATE_RV=0: one row per lane, tunable; 2 x 64 fp64 accumulators per lane spill: 6.2 ms
@@ -431,6 +625,29 @@ static int block_update_impl(int64_t n, int64_t k, const void *X_, int64_t ldx, 
   int64_t kmax = (int64_t)(kRingSlotBytes / (mpad * sizeof(T))) / kUnrollK * kUnrollK;
   RLH_REQUIRE(kmax >= kUnrollK, "rlh_block_update: %lld output vectors exceed the staging slot", (long long)m);
   if (kmax > 1024) kmax = 1024;
+  if constexpr (!DType<DT>::cplx) {
+    // Out += X Q on the matrix cores as ONE product [X | Out] [Q; I]: the result block rides the same two-set
+    // fragment pipeline as the source (its loads are issued a tile ahead, like X's) instead of being read inside the
+    // column-tile loop right where it is needed; the extra m k-steps of arithmetic are free at these sizes.
+    const int64_t kp1 = (k + kUnrollK - 1) / kUnrollK * kUnrollK;
+    if (beta && k > 0 && k <= kmax && env_flag("RLH_UPDATE_FOLD", 1) &&
+        (size_t)((kp1 + m + 3) * mpad) * sizeof(T) <= kRingSlotBytes &&
+        update_stream_ok<T>(X, ldx, Out, ldo, Out, ldo, Out, ldo, (int)k, (int)m, (int)kp1, (int)m)) {
+      const int64_t rows = kp1 + (m + 3) / 4 * 4;
+      int slot; void *h, *d;
+      if (int rc = ring_acquire((size_t)(rows * mpad) * sizeof(T), &slot, &h, &d)) return rc;
+      T *qh = (T *)h;
+      memset(qh, 0, (size_t)(rows * mpad) * sizeof(T));
+      for (int64_t i = 0; i < k; ++i)
+        for (int64_t j = 0; j < m; ++j) qh[i * mpad + j] = HostScalar<T>::mul(alpha, q[i * q_rs + j * q_cs]);
+      for (int64_t j = 0; j < m; ++j) qh[(kp1 + j) * mpad + j] = (T)1;
+      if (int rc = ring_commit(slot, (size_t)(rows * mpad) * sizeof(T))) return rc;
+      if (int rc = launch_update_stream<T>(X, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)k, (int)m, 0, Out, ldo, (int)m,
+                                           (int)kp1, Out, ldo, (int)m))
+        return rc;
+      return ring_release(slot);
+    }
+  }
   for (int64_t k0 = 0; k0 < k || k0 == 0; k0 += kmax) {
     const int64_t kk = (k - k0) < kmax ? (k - k0) : kmax;
     const int64_t kpad = (kk + kUnrollK - 1) / kUnrollK * kUnrollK;

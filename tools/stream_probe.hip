@@ -319,6 +319,36 @@ __global__ __launch_bounds__(64 * WAVES) void read_stream_like(const u4 *x, cons
   if (s.x == 0x12345678u) out[0] = s;
 }
 
+
+// 14. row-wise copy in the MFMA fragment shape: one wave instruction = 4 columns x 256 contiguous bytes (lane l: piece
+//     l & 15 of column 4 q + (l >> 4)); LDRUN / STRUN choose that shape (true) or 1-KB runs of one column (false)
+//     separately for the loads and the stores.  A wave owns 128 rows (1 KB per column) either way.
+template <bool NTL, bool NTS, bool LDFRAG, bool STFRAG, int C>
+__global__ __launch_bounds__(256) void rowwise_frag(const u4 *x, u4 *y, int64_t ldw, int64_t nw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r0 = wave * 64;                          // first 16-byte word of this wave's rows
+  if (r0 + 64 > nw) return;
+#pragma unroll
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    u4 v[4];
+    // 4 columns x 64 words: either column-at-a-time (instruction u = column c0 + u, lane = word) or fragment shape
+    // (instruction u = words 16 u .. 16 u + 15 of the four columns, lane l: column c0 + (l >> 4), word 16 u + (l & 15))
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = LDFRAG ? ld<NTL, NTS>(x + r0 + 16 * u + (lane & 15) + (c0 + (lane >> 4)) * ldw)
+                    : ld<NTL, NTS>(x + r0 + lane + (c0 + u) * ldw);
+    if (LDFRAG != STFRAG) {
+      // (a real kernel would transpose 4 x 4 lane groups here: v_permlane16/32_swap; the probe only measures memory)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (STFRAG) st<NTL, NTS>(y + r0 + 16 * u + (lane & 15) + (c0 + (lane >> 4)) * ldw, v[u]);
+      else st<NTL, NTS>(y + r0 + lane + (c0 + u) * ldw, v[u]);
+    }
+  }
+}
+
 template <typename F> static double timed(F f, int reps = 9) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -345,23 +375,13 @@ int main(int argc, char **argv) {
   auto report = [&](const char *name, double ms, double gb) { printf("%-58s %7.3f ms  %7.1f GB/s\n", name, ms, gb / ms * 1e3); fflush(stdout); };
   const int64_t tot = nw * m;
   report("copy_flat nt ld+st", timed([&] { hipLaunchKernelGGL((copy_flat<true, true>), dim3((tot + 255) / 256), dim3(256), 0, 0, x, y, tot); }), 2 * GB);
-  // does the row-wise rate depend on the leading dimension (how the 32 + 32 column streams fall onto channels / banks)?
-  // blocks re-allocated with room for the largest padding; ld = nw + pad 16-byte words
-  CK(hipFree(x)); CK(hipFree(y));
-  const int64_t maxpad = 1 << 20;
-  CK(hipMalloc(&x, (size_t)(nw + maxpad) * m * 16)); CK(hipMalloc(&y, (size_t)(nw + maxpad) * m * 16));
-  CK(hipMemset(x, 1, (size_t)(nw + maxpad) * m * 16)); CK(hipMemset(y, 2, (size_t)(nw + maxpad) * m * 16));
-  const double *xd = (const double *)x; double *yd = (double *)y;
-  Q8 qa; for (int i = 0; i < 8; ++i) qa.q[i] = 1.0 + i;
-  for (int64_t pad : {0, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576, 13, 1000, 77777}) {
-    const int64_t ldp = nw + pad;
-    char nm[160];
-    snprintf(nm, sizeof nm, "ld = n + %lld B: FLAT row-wise copy U=4 nt", (long long)pad * 16);
-    report(nm, timed([&] { hipLaunchKernelGGL((rowwise_wide<true, true, 32, 4, 1>), dim3((nw + 255) / 256), dim3(256), 0, 0, x, y, ldp, nw); }), 2 * GB);
-    snprintf(nm, sizeof nm, "ld = n + %lld B: update-like (1024 FMA/row, nt)", (long long)pad * 16);
-    report(nm, timed([&] { hipLaunchKernelGGL((rowwise_fma<0, true>), dim3((n / 2 + 255) / 256), dim3(256), 0, 0, xd, yd, 2 * ldp, n, qa, (const double *)nullptr); }), 2 * GB);
-    snprintf(nm, sizeof nm, "ld = n + %lld B: write row-wise nt", (long long)pad * 16);
-    report(nm, timed([&] { hipLaunchKernelGGL((write_rowwise<true, 32>), dim3((nw + 255) / 256), dim3(256), 0, 0, y, ldp, nw); }), GB);
+  const dim3 gw((nw / 64 + 3) / 4);
+  for (int rep = 0; rep < 2; ++rep) {
+    report("row-wise copy, loads 1-KB runs, stores 1-KB runs (nt)", timed([&] { hipLaunchKernelGGL((rowwise_frag<true, true, false, false, 32>), gw, dim3(256), 0, 0, x, y, ldw, nw); }), 2 * GB);
+    report("row-wise copy, loads 4 x 256 B,  stores 1-KB runs (nt)", timed([&] { hipLaunchKernelGGL((rowwise_frag<true, true, true, false, 32>), gw, dim3(256), 0, 0, x, y, ldw, nw); }), 2 * GB);
+    report("row-wise copy, loads 1-KB runs, stores 4 x 256 B  (nt)", timed([&] { hipLaunchKernelGGL((rowwise_frag<true, true, false, true, 32>), gw, dim3(256), 0, 0, x, y, ldw, nw); }), 2 * GB);
+    report("row-wise copy, loads 4 x 256 B,  stores 4 x 256 B  (nt)", timed([&] { hipLaunchKernelGGL((rowwise_frag<true, true, true, true, 32>), gw, dim3(256), 0, 0, x, y, ldw, nw); }), 2 * GB);
+    report("row-wise copy, loads 4 x 256 B,  stores 4 x 256 B  (plain)", timed([&] { hipLaunchKernelGGL((rowwise_frag<false, false, true, true, 32>), gw, dim3(256), 0, 0, x, y, ldw, nw); }), 2 * GB);
   }
   return 0;
 }
