@@ -387,7 +387,7 @@ static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, cons
 // which streams as fast as 1-KB runs of one column (5.8 TB/s for the bare 32 + 32 column copy of this shape,
 // tools/stream_probe.hip section 14).  A wave walks TPW consecutive tiles of 16 V rows with the X fragments of the
 // NEXT tile in flight during the MFMAs and stores of the current one (two register sets); the coefficients sit in
-// the LDS in fragment order [column tile][k-step][lane], re-laid-out once per workgroup (4 waves x TPW tiles, so that
+// the LDS in fragment order [column tile][k-step][lane], re-laid-out once per workgroup (4 waves x 8 tiles, so that
 // this costs a few percent of the traffic), one ds_read per V MFMAs.  No run-time switch touches a load or store.
 // What it replaces: the SGPR-fed VALU kernel above issues 2 k m v_fma per row; for results of more than 32 columns
 // its accumulators no longer fit beside 16-byte accesses, it falls back to 8 bytes per lane and is bound by its
@@ -397,8 +397,8 @@ static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, cons
 constexpr int kUpdTilesPerWave = 8;
 template <typename R, int KS, bool BETA, bool NT>
 __global__ __launch_bounds__(256) void block_update_stream_kernel(const R *__restrict__ X, int64_t ldx, int k1, int ks1,
-                                                                  const R *X2, int64_t ldx2, int k2, int ks2,   // (X2 may BE Out:
-                                                                  R *Out, int64_t ldo, R *Out2,                  //  the folded add)
+                                                                  const R *__restrict__ X2, int64_t ldx2, int k2, int ks2,
+                                                                  R *__restrict__ Out, int64_t ldo, R *__restrict__ Out2,
                                                                   int64_t ldo2, int msplit, const R *__restrict__ Q, int ldq,
                                                                   int64_t n, int m) {
   using M = Mfma16x4<R>;
@@ -625,29 +625,8 @@ static int block_update_impl(int64_t n, int64_t k, const void *X_, int64_t ldx, 
   int64_t kmax = (int64_t)(kRingSlotBytes / (mpad * sizeof(T))) / kUnrollK * kUnrollK;
   RLH_REQUIRE(kmax >= kUnrollK, "rlh_block_update: %lld output vectors exceed the staging slot", (long long)m);
   if (kmax > 1024) kmax = 1024;
-  if constexpr (!DType<DT>::cplx) {
-    // Out += X Q on the matrix cores as ONE product [X | Out] [Q; I]: the result block rides the same two-set
-    // fragment pipeline as the source (its loads are issued a tile ahead, like X's) instead of being read inside the
-    // column-tile loop right where it is needed; the extra m k-steps of arithmetic are free at these sizes.
-    const int64_t kp1 = (k + kUnrollK - 1) / kUnrollK * kUnrollK;
-    if (beta && k > 0 && k <= kmax && env_flag("RLH_UPDATE_FOLD", 1) &&
-        (size_t)((kp1 + m + 3) * mpad) * sizeof(T) <= kRingSlotBytes &&
-        update_stream_ok<T>(X, ldx, Out, ldo, Out, ldo, Out, ldo, (int)k, (int)m, (int)kp1, (int)m)) {
-      const int64_t rows = kp1 + (m + 3) / 4 * 4;
-      int slot; void *h, *d;
-      if (int rc = ring_acquire((size_t)(rows * mpad) * sizeof(T), &slot, &h, &d)) return rc;
-      T *qh = (T *)h;
-      memset(qh, 0, (size_t)(rows * mpad) * sizeof(T));
-      for (int64_t i = 0; i < k; ++i)
-        for (int64_t j = 0; j < m; ++j) qh[i * mpad + j] = HostScalar<T>::mul(alpha, q[i * q_rs + j * q_cs]);
-      for (int64_t j = 0; j < m; ++j) qh[(kp1 + j) * mpad + j] = (T)1;
-      if (int rc = ring_commit(slot, (size_t)(rows * mpad) * sizeof(T))) return rc;
-      if (int rc = launch_update_stream<T>(X, ldx, Out, ldo, (const T *)d, (int)mpad, n, (int)k, (int)m, 0, Out, ldo, (int)m,
-                                           (int)kp1, Out, ldo, (int)m))
-        return rc;
-      return ring_release(slot);
-    }
-  }
+  // (Folding the add into the product -- Out += X Q as [X | Out] [Q; I], so that the result block rides the fragment
+  // pipeline of the sources -- was measured and dropped: 1.446 vs 1.443 ms.)
   for (int64_t k0 = 0; k0 < k || k0 == 0; k0 += kmax) {
     const int64_t kk = (k - k0) < kmax ? (k - k0) : kmax;
     const int64_t kpad = (kk + kUnrollK - 1) / kUnrollK * kUnrollK;
