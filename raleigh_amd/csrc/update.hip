@@ -271,7 +271,7 @@ template <> struct Mfma16x4<float> {
 
 constexpr int kMfmaUpdKS = 32;               // k-steps (of 4 columns) whose X fragments a wave keeps in registers
 
-template <typename T, typename R, bool BETA>
+template <typename T, typename R, bool BETA, int KS>
 __global__ __launch_bounds__(256) void block_update_mfma_kernel(const T *__restrict__ X, int64_t ldx, int k1, int ks1,
                                                                 const T *__restrict__ X2, int64_t ldx2, int k2, int ks2,
                                                                 T *__restrict__ Out, int64_t ldo, T *__restrict__ Out2,
@@ -294,12 +294,12 @@ __global__ __launch_bounds__(256) void block_update_mfma_kernel(const T *__restr
   const int64_t ntiles_rows = (n + 15) / 16;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6), nwaves = (int64_t)gridDim.x * 4;
   const int kk = lane >> 4, rl = lane & 15;
-  T xf[kMfmaUpdKS];
+  T xf[KS];
   auto load_x = [&](int64_t rt) {
     int64_t r = rt * 16 + rl;
     r = r < n ? r : n - 1;                                 // rows past the end repeat the last (never stored)
 #pragma unroll
-    for (int s = 0; s < kMfmaUpdKS; ++s) {
+    for (int s = 0; s < KS; ++s) {
       if (s < nks) {                                       // (workgroup-uniform)
         const bool first = s < ks1;
         int c = first ? 4 * s + kk : 4 * (s - ks1) + kk;
@@ -312,21 +312,29 @@ __global__ __launch_bounds__(256) void block_update_mfma_kernel(const T *__restr
   for (int64_t rt = wave_id; rt < ntiles_rows; rt += nwaves) {
     load_x(rt);
     const int64_t row = rt * 16 + rl;
+    // beta = 1: the result fragments of column tile t + 1 are requested before the MFMAs of tile t (unconditional
+    // loads of clamped addresses: no branch between a load and its use)
+    const int64_t rowc = row < n ? row : n - 1;
+    T onext[4];
+    auto load_out = [&](int t_, T (&o)[4]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int j = 16 * t_ + M::out_row(lane, g);
+        j = j < m ? j : m - 1;
+        o[g] = j < msplit ? Out[rowc + (int64_t)j * ldo] : Out2[rowc + (int64_t)(j - msplit) * ldo2];
+      }
+    };
+    if (BETA) load_out(0, onext);
     for (int t = 0; t < ntile; ++t) {
       acc_t dr = {(R)0, (R)0, (R)0, (R)0}, di = {(R)0, (R)0, (R)0, (R)0};
       if (BETA) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int j = 16 * t + M::out_row(lane, g);
-          if (j < m && row < n) {
-            const T o = j < msplit ? Out[row + (int64_t)j * ldo] : Out2[row + (int64_t)(j - msplit) * ldo2];
-            dr[g] = o.re; di[g] = o.im;
-          }
-        }
+        for (int g = 0; g < 4; ++g) { dr[g] = onext[g].re; di[g] = onext[g].im; }
+        load_out(t + 1 < ntile ? t + 1 : t, onext);
       }
       const T *qt = qf + (int64_t)t * nks * 64 + lane;
 #pragma unroll
-      for (int s = 0; s < kMfmaUpdKS; ++s) {
+      for (int s = 0; s < KS; ++s) {
         if (s < nks) {
           const T q = qt[s * 64];
           const T x = xf[s];
@@ -348,35 +356,51 @@ __global__ __launch_bounds__(256) void block_update_mfma_kernel(const T *__restr
   }
 }
 
-// The matrix-core path: complex types, every k-step in registers, Q in the LDS.
-template <typename T>
-static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
-                              int beta, const T *X2, int64_t ldx2, int k2, int kpad, T *Out2, int64_t ldo2, int msplit) {
+// The matrix-core path: complex types, every k-step in registers (KS bounds them at compile time: 8, 16 or 32 k-steps,
+// so that k <= 64 leaves room for two or three waves per SIMD), Q in the LDS.
+template <typename T, int KS>
+static int launch_update_mfma_ks(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
+                                 int beta, const T *X2, int64_t ldx2, int k2, int ks1, int ks2, T *Out2, int64_t ldo2,
+                                 int msplit, size_t lds) {
   using R = decltype(T{}.re);
   Context &c = ctx();
-  const int ks1 = X2 && k2 > 0 ? kpad / 4 : (k + 3) / 4, ks2 = X2 && k2 > 0 ? (k2 + 3) / 4 : 0;
-  const int ntile = (m + 15) / 16;
-  const size_t lds = (size_t)ntile * (ks1 + ks2) * 64 * sizeof(T);
   static bool attr = false;
   if (!attr) {
-    RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_update_mfma_kernel<T, R, false>),
+    RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_update_mfma_kernel<T, R, false, KS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_update_mfma_kernel<T, R, true>),
+    RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&block_update_mfma_kernel<T, R, true, KS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  int64_t nb = (int64_t)c.num_cu * (lds <= 80 * 1024 ? 2 : 1);
+  int64_t per_cu = lds > 0 ? (int64_t)(160 * 1024 / lds) : 4;
+  const int cap = env_flag("RLH_UPDATE_MFMA_WG", 2);      // resident workgroups per CU (tunable)
+  if (per_cu > cap) per_cu = cap;
+  if (per_cu < 1) per_cu = 1;
+  int64_t nb = (int64_t)c.num_cu * per_cu;
   const int64_t need = ((n + 15) / 16 + 3) / 4;
   if (nb > need) nb = need;
   if (nb < 1) nb = 1;
   if (beta)
-    hipLaunchKernelGGL((block_update_mfma_kernel<T, R, true>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, k, ks1, X2, ldx2,
-                       k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m);
+    hipLaunchKernelGGL((block_update_mfma_kernel<T, R, true, KS>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, k, ks1, X2,
+                       ldx2, k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m);
   else
-    hipLaunchKernelGGL((block_update_mfma_kernel<T, R, false>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, k, ks1, X2, ldx2,
-                       k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m);
+    hipLaunchKernelGGL((block_update_mfma_kernel<T, R, false, KS>), dim3((unsigned)nb), dim3(256), lds, c.stream, X, ldx, k, ks1, X2,
+                       ldx2, k2, ks2, Out, ldo, Out2, ldo2, msplit, Qd, ldq, n, m);
   RLH_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T>
+static int launch_update_mfma(const T *X, int64_t ldx, T *Out, int64_t ldo, const T *Qd, int ldq, int64_t n, int k, int m,
+                              int beta, const T *X2, int64_t ldx2, int k2, int kpad, T *Out2, int64_t ldo2, int msplit) {
+  const int ks1 = X2 && k2 > 0 ? kpad / 4 : (k + 3) / 4, ks2 = X2 && k2 > 0 ? (k2 + 3) / 4 : 0;
+  const int ntile = (m + 15) / 16;
+  const size_t lds = (size_t)ntile * (ks1 + ks2) * 64 * sizeof(T);
+  if (ks1 + ks2 <= 8)
+    return launch_update_mfma_ks<T, 8>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, ks1, ks2, Out2, ldo2, msplit, lds);
+  if (ks1 + ks2 <= 16)
+    return launch_update_mfma_ks<T, 16>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, ks1, ks2, Out2, ldo2, msplit, lds);
+  return launch_update_mfma_ks<T, 32>(X, ldx, Out, ldo, Qd, ldq, n, k, m, beta, X2, ldx2, k2, ks1, ks2, Out2, ldo2, msplit, lds);
 }
 
 // ---------------------------------------------------------------- real block update on the matrix cores
