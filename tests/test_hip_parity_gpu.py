@@ -148,7 +148,8 @@ def test_unaligned_leading_dimension(key):
 
 @pytest.mark.parametrize('key', KEYS)
 @pytest.mark.parametrize('n,k,m', [(1, 1, 1), (777, 5, 3), (10000, 16, 16), (30011, 32, 32), (4096, 40, 9),
-                                   (3000, 3, 70), (2048, 300, 20)])
+                                   (3000, 3, 70), (2048, 300, 20), (5, 8, 8), (33, 12, 20), (1023, 64, 64),
+                                   (9001, 9, 64), (20002, 128, 17), (66, 37, 33)])
 def test_block_update_vs_oracle(key, n, k, m):
     from raleigh_amd.algebra.hip import Vectors
     rng = np.random.default_rng(n + k + m)
@@ -620,7 +621,8 @@ def test_spmm_interior_boundary_parts(spmm_format, key):
 
 
 @pytest.mark.parametrize('key', KEYS)
-@pytest.mark.parametrize('shape', [(7, 5, 9, 4), (16, 16, 16, 16), (3, 20, 10, 27)])
+@pytest.mark.parametrize('shape', [(7, 5, 9, 4), (16, 16, 16, 16), (3, 20, 10, 27), (32, 32, 40, 24), (30, 34, 17, 33),
+                                   (64, 64, 32, 32)])
 def test_combine2_two_outputs_one_pass(key, shape):
     """rlh_block_update2x2 / Vectors.combine2: [A | B] = X qx + Y qy in one pass, against the oracle
     (odd row count: the 16-byte row groups end in a partial one)."""
