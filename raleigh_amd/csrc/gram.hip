@@ -55,6 +55,7 @@ struct GramArgs {
   void *partials;     // [npanels][gridDim.x][VY][VX] reals
   int nxs, nys;       // segments of the X / Y window (MULTI kernels only)
   int nt;             // non-temporal loads of the blocks (each byte is read once per launch)
+  int xal;            // streaming kernel: the X window IS the columns [xal, xal + mx) of the Y window (or -1)
   GramSeg xs[kGramSegs], ys[kGramSegs];
 };
 
@@ -497,22 +498,27 @@ static int gram_nt(int64_t bytes) {
 // waves and others three, and the launch took as long as its fullest CU (0.90-0.95 ms instead of 0.76 ms).
 constexpr int gram_stream_waves(int ncol) { return ncol <= 16 ? 16 : (ncol <= 32 ? 8 : 4); }
 
-template <typename R, int TB, int NYC, int NXC, bool NT>
-__global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream_kernel(GramArgs a) {
+// XAL: the X window is a block that also sits in the Y window ([X | Y]^H Y, [AX | X]^H X of the solver's stacked
+// reductions), at columns a.xal .. (a multiple of 16): it is staged ONCE and the B fragments are read out of the Y
+// image (16 instead of 24 loads per tile; such calls took 0.92-1.0 ms where two distinct blocks stream in 0.77 ms).
+template <typename R, int TB, int NYC, int NXC, bool NT, bool XAL = false>
+__global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void gram_stream_kernel(GramArgs a) {
   using M = Mfma16<R>;
   using acc_t = typename M::acc_t;
   constexpr bool SELF = NYC == 0;
   constexpr int RPU = 16 / (int)sizeof(R);      // rows per 16-byte piece
   constexpr int NP = TB / 16;                   // pieces per column and tile
   constexpr int ROWS = NP * RPU;                // rows per tile
-  constexpr int NCOL = NYC + NXC;               // staged columns: Y (NYC) then X (NXC = 16 or 32)
+  constexpr int NCOL = XAL ? NYC : NYC + NXC;   // staged columns: Y (NYC) then X (NXC = 16, 32 or 64; none if aliased)
   constexpr int CPL = 64 / NP;                  // columns covered by one load instruction of the wave
   constexpr int NL = NCOL / CPL;                // loads per lane and tile
   constexpr int KS = ROWS / 4;                  // MFMA k-steps per tile
   constexpr int SW = NP / 16;
   constexpr int PJ = NXC / 16, PI = SELF ? PJ : NYC / 16;
   static_assert(NP >= 16 && NP <= 64 && 64 % NP == 0 && NCOL % CPL == 0, "tile shape");
-  constexpr int WPG = gram_stream_waves(NYC + NXC);
+  // (XAL: two waves per SIMD -- with half the bytes per MFMA the launch is no longer purely memory-bound, and a
+  // second wave fills the first one's waits)
+  constexpr int WPG = XAL ? 8 : gram_stream_waves(NYC + NXC);
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   char *lds = lds_all + (threadIdx.x >> 6) * (NCOL * TB);   // this wave's private image
   typedef R vec_t __attribute__((ext_vector_type(RPU)));
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream
 #pragma unroll
     for (int j = 0; j < PJ; ++j) acc[i][j] = acc_t{(R)0, (R)0, (R)0, (R)0};
   const int fr = lane & 15, fk = lane >> 4;
+  const int xcol0 = XAL ? a.xal : NYC;          // first image column of the X window
   // byte offset of this lane's fragment element of k-step s inside a column image
   auto frag_off = [&](int s) -> int {
     if constexpr (sizeof(R) == 8) return (((2 * s + (fk >> 1)) ^ (fr * SW)) << 4) + (fk & 1) * 8;
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream
       const int off = frag_off(s);
       R fa[PI], fb[PJ];
 #pragma unroll
-      for (int j = 0; j < PJ; ++j) fb[j] = *reinterpret_cast<const R *>(lds + (NYC + j * 16 + fr) * TB + off);
+      for (int j = 0; j < PJ; ++j) fb[j] = *reinterpret_cast<const R *>(lds + (xcol0 + j * 16 + fr) * TB + off);
 #pragma unroll
       for (int i = 0; i < PI; ++i) {
         if constexpr (SELF) fa[i] = fb[i];
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(64 * gram_stream_waves(NYC + NXC)) void gram_stream
   const int64_t nfull = a.n / ROWS, G = (int64_t)gridDim.x * WPG, t0 = (int64_t)blockIdx.x * WPG + (threadIdx.x >> 6);
   const int64_t count = t0 < nfull ? (nfull - t0 + G - 1) / G : 0;
   auto tile_of = [&](int64_t j) -> int64_t { return t0 + (j < count ? j : count - 1) * G; };
-  if constexpr (NCOL >= 128) {
+  if constexpr (NCOL >= 128 || XAL) {           // (XAL: two waves per SIMD, 256 registers each: one set)
     // (128 staged columns: one register set of 32 pieces -- two would spill; a tile is 32 KB, so one tile per wave in
     // flight during its compute phase is as many bytes per CU as two tiles of the 64-column shapes)
     if (count > 0) {
@@ -687,6 +694,7 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   if (nbx * wpg > ntiles) nbx = (ntiles + wpg - 1) / wpg;
   if (nbx < 1) nbx = 1;
   const int64_t nparts = nbx * wpg;
+  int64_t nparts_alias = 0;
   const int VY = self ? nxc : nyc;
   RLH_REQUIRE((size_t)nparts * VY * nxc * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
 #define RLH_GS1(NYC_, NXC_, NT_)                                                                                       \
@@ -704,7 +712,28 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   do {                                                                                                                 \
     if (a.nt & 1) RLH_GS1(NYC_, NXC_, true); else RLH_GS1(NYC_, NXC_, false);                                          \
   } while (0)
-  if (nxc == 16) {
+  if (a.xal >= 0 && nyc == 64 && nxc == 32) {
+    // (the image and the launch are those of the 64-column Y window alone)
+    lds = (size_t)8 * 64 * TB;
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    nbx = c.num_cu;
+    if (nbx * 8 > ntiles) nbx = (ntiles + 7) / 8;
+    if (nbx < 1) nbx = 1;
+    nparts_alias = nbx * 8;
+#define RLH_GSA(NT_)                                                                                                   \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<R, TB, 64, 32, NT_, true>),       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gram_stream_kernel<R, TB, 64, 32, NT_, true>), dim3((unsigned)nbx), dim3(64 * 8),                    \
+                       lds, c.stream, a);                                                                              \
+  } while (0)
+    if (a.nt & 1) RLH_GSA(true); else RLH_GSA(false);
+#undef RLH_GSA
+  } else if (nxc == 16) {
     if (nyc == 0) RLH_GS(0, 16); else if (nyc == 16) RLH_GS(16, 16); else if (nyc == 32) RLH_GS(32, 16); else RLH_GS(64, 16);
   } else if (nxc == 32) {
     if (nyc == 0) RLH_GS(0, 32); else if (nyc == 16) RLH_GS(16, 32); else if (nyc == 32) RLH_GS(32, 32); else RLH_GS(64, 32);
@@ -715,7 +744,8 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
 #undef RLH_GS1
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
-  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work, (int)nparts, 1, VY, nxc,
+  hipLaunchKernelGGL((gram_finalize<DT>), dim3((total + 3) / 4), dim3(256), 0, c.stream, c.work,
+                     (int)(nparts_alias ? nparts_alias : nparts), 1, VY, nxc,
                      (int)my, (int)mx, d_out, a.same);
   RLH_HIP(hipGetLastError());
   return 0;
@@ -745,6 +775,7 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
     // wave -- 8 MB at 32 x 32 -- and measured 44 vs 39 us at n = 262144, 21 vs 14 us at n = 27000)
     if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8) && (a.nt || stream > 1)) {
       a.npj = 1;
+      a.xal = -1;
       a.nxs = a.nys = 1;
       a.xs[0] = GramSeg{X, ldx, 0};
       a.ys[0] = GramSeg{Y, ldy, 0};
@@ -836,6 +867,10 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
     const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
     if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8) && (a.nt || stream > 1)) {
       a.npj = 1;
+      a.xal = -1;
+      if (nx == 1 && mxt > 16 && mxt <= 32 && myt > 32)       // the X block is one of the Y window's blocks
+        for (int k2 = 0; k2 < ny; ++k2)
+          if (Y[k2] == X[0] && ldy[k2] == ldx[0] && my[k2] == mx[0] && a.ys[k2].c0 % 16 == 0) a.xal = a.ys[k2].c0;
       return gram_stream_launch<DT>(a, myt, mxt, d_out);
     }
   }

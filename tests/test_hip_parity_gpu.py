@@ -112,6 +112,27 @@ def test_gram_streaming_kernel_shapes(key, n, mx, my, monkeypatch):
     assert cases.rel(dd, ops.dots(x64, x64)) < tol
 
 
+@pytest.mark.parametrize('key', ['d', 's'])
+@pytest.mark.parametrize('n,m', [(20011, 32), (4099, 24), (1000, 17)])
+def test_gram_streaming_kernel_shared_block(key, n, m, monkeypatch):
+    """Stacked requests whose right block is also one of the left blocks ([X | Y]^H Y, [AX | X]^H X): the streaming
+    kernel stages that block once and reads both fragment sides out of the same image."""
+    from raleigh_amd.algebra.hip import Vectors
+    monkeypatch.setenv('RLH_GRAM_STREAM', '2')
+    rng = np.random.default_rng(n + m)
+    x, y = rnd((m, n), key, rng), rnd((32, n), key, rng)
+    X, Y = Vectors(x), Vectors(y)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    tol = tol_for(key, n)
+    for rights, lefts, r64, l64 in (([X], [Y, X], x64, np.concatenate((y64, x64))),       # the shared block second
+                                    ([Y], [Y, X], y64, np.concatenate((y64, x64)))):      # ... and first (offset 0)
+        rb = X.reduction_batch()
+        rb.gram(rights, lefts)
+        got, = rb.run()
+        assert got.shape == (l64.shape[0], r64.shape[0])
+        assert cases.rel(got, ops.gram(r64, l64)) < tol
+
+
 @pytest.mark.parametrize('key', KEYS)
 def test_unaligned_leading_dimension(key):
     """A Vectors view of a C-ordered Matrix has ld = padded row length but a window of a
