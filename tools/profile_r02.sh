@@ -25,11 +25,10 @@ done
 run c5_stats "" python3 $R/tools/microbench.py --n 2000376 --m 64 --dtype z
 run c5_fetch FETCH_SIZE python3 $R/tools/microbench.py --n 2000376 --m 64 --dtype z --only gram
 run c5_mfma "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" python3 $R/tools/microbench.py --n 2000376 --m 64 --dtype z --only "X"
-# (the profiler segfaults inside hipGraphLaunch when the captured level launches are traced: plain launches here)
-export RLH_SPTRSV_NO_GRAPH=1
+# (the profiler segfaults inside hipGraphLaunch when the captured level launches are traced: the library falls back to
+# plain launches when it sees rocprofv3's ROCP_TOOL_LIBRARIES)
 run ilu_stats "" python3 $R/tools/ilu_bench.py lap100
 run ilu_fe_stats "" python3 $R/tools/ilu_bench.py fe
-unset RLH_SPTRSV_NO_GRAPH
 run pca_stats "" python3 $R/tools/pca_bench.py --gemm-only
 run pca_mfma "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" python3 $R/tools/pca_bench.py --gemm-only
 python3 - <<PY
