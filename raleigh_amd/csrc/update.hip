@@ -12,6 +12,8 @@
 // Replaces: cudaMalloc + H2D + cublas?gemm(NoTrans, Trans|NoTrans) + cudaFree
 // (raleigh/algebra/dense_cublas.py:271-342), m axpy / scal / copy calls
 // (dense_cublas.py:133-172, 343-350).
+#include <algorithm>
+
 #include "common.h"
 
 namespace rlh {
@@ -1141,6 +1143,21 @@ int rlh_block_update2x2(int dtype, int64_t n, int64_t k1, const void *X1, int64_
               "rlh_block_update2x2: an output window overlaps an input window or the other output");
   const double one[2] = {1.0, 0.0};
   int rc = 0;
+  // Complex blocks whose combined coefficients exceed the LDS of the matrix-core kernel (k1 + k2 = 128, ma + mb = 128
+  // complex128: 262 KB) would fall to the VALU kernel in panels of 16 columns, each re-reading both sources (5.4 ms at
+  // n = 2 x 10^6); each result block alone fits (131 KB): two matrix-core passes, 4.7 ms.
+  if (dtype == RLH_C || dtype == RLH_Z) {
+    const int64_t ks = (k1 + 3) / 4 + (k2 + 3) / 4;
+    const int64_t both = ((ma + mb + 15) / 16) * ks * 64 * es, worst = ((std::max(ma, mb) + 15) / 16) * ks * 64 * es;
+    if (ks <= kMfmaUpdKS && both > 160 * 1024 && worst <= 160 * 1024) {
+      RLH_DISPATCH(dtype, block_update2_impl, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, ma, OutA,
+                   ldoa, one, 0, nullptr, 0, -1)
+      if (rc) return rc;
+      RLH_DISPATCH(dtype, block_update2_impl, n, k1, X1, ldx1, (const char *)q1 + ma * q1_cs * es, q1_rs, q1_cs, k2, X2, ldx2,
+                   (const char *)q2 + ma * q2_cs * es, q2_rs, q2_cs, mb, OutB, ldob, one, 0, nullptr, 0, -1)
+      return rc;
+    }
+  }
   RLH_DISPATCH(dtype, block_update2_impl, n, k1, X1, ldx1, q1, q1_rs, q1_cs, k2, X2, ldx2, q2, q2_rs, q2_cs, ma + mb,
                OutA, ldoa, one, 0, OutB, ldob, ma)
   return rc;

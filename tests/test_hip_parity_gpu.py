@@ -643,7 +643,7 @@ def test_spmm_interior_boundary_parts(spmm_format, key):
 
 @pytest.mark.parametrize('key', KEYS)
 @pytest.mark.parametrize('shape', [(7, 5, 9, 4), (16, 16, 16, 16), (3, 20, 10, 27), (32, 32, 40, 24), (30, 34, 17, 33),
-                                   (64, 64, 32, 32)])
+                                   (64, 64, 32, 32), (64, 64, 64, 64), (60, 64, 64, 50)])
 def test_combine2_two_outputs_one_pass(key, shape):
     """rlh_block_update2x2 / Vectors.combine2: [A | B] = X qx + Y qy in one pass, against the oracle
     (odd row count: the 16-byte row groups end in a partial one)."""
