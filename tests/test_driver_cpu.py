@@ -432,3 +432,31 @@ def test_shift_invert_moves_no_block_across_pcie(fake, golden_dir):
     assert abs(out[True][1] - 17) <= 3
     assert out[True][2] <= 4                              # start block in, eigenvectors out: nothing per iteration
     assert out[False][2] >= 2 * out[False][1]             # the host solve: two transfers per application
+
+
+def test_pivoted_cholesky_condition_control():
+    """The kept block of the pivoted factor is well conditioned (reciprocal condition number of U^H U above eps),
+    reproduces its block of the permuted Gram matrix, and everything dropped is zero -- for spectra decaying over 2 to
+    14 orders of magnitude, with and without an unpivoted leading block (the bisection over the number of kept
+    columns replaces the reference's one-at-a-time search, solver.py:1749-1826)."""
+    from raleigh_amd.core.solver import _pivoted_cholesky
+    rng = np.random.default_rng(7)
+    seen_drop = False
+    for trial in range(16):
+        n, k = 24, int(rng.integers(0, 8))
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        d = np.logspace(0, -rng.uniform(2, 14), n)
+        G = (Q * d) @ Q.T
+        G = (G + G.T) / 2
+        eps = 1e-8
+        U, ind, dropped = _pivoted_cholesky(G, k, eps)
+        kept = n - k - dropped
+        seen_drop = seen_drop or dropped > 0
+        Gp = G[np.ix_(ind, ind)]
+        if k + kept > 0:
+            blk = U[:k + kept, :k + kept]
+            sv = np.linalg.svd(blk, compute_uv=False)
+            assert (sv[-1] / sv[0]) ** 2 > eps
+            assert np.allclose(blk.T @ blk, Gp[:k + kept, :k + kept], atol=1e-10 * np.abs(G).max())
+        assert not U[k + kept:].any() and not U[:, k + kept:].any()
+    assert seen_drop
