@@ -78,7 +78,7 @@ struct GramArgs {
 // operands: at m = k = 64 complex128 that is twice the bytes, and the MFMA pipes idle while the one
 // resident workgroup per CU stages (measured 2.08 ms = 40 % of the fp64 MFMA rate, 25 % of the HBM rate;
 // the two bounds are 0.83 and 0.82 ms).  Chunks are 256-byte column pieces so that two workgroups fit a CU.
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false, bool SYMS = false>
 __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2 && PJ <= 2) ? 3 : 1)) void gram_kernel(GramArgs a) {
   using T = typename DType<DT>::T;
   using R = typename DType<DT>::R;
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2
   const int lane = tid & 63, wave = tid >> 6;
   const int panel = blockIdx.y;
   const int pi = panel / a.npj, pj = panel % a.npj;
-  const bool same_panel = MODE == 2 ? true : (MODE == 1 ? false : (a.same && (pi == pj) && (PI == PJ)));
+  // (SYMS: the instantiation for the self-Gram of ONE square quadrant panel)
+  const bool same_panel = SYMS ? true : (MODE == 2 ? true : (MODE == 1 ? false : (a.same && (pi == pj) && (PI == PJ))));
   const int cy0 = pi * CY, cx0 = pj * CX;        // first T column of the panels
   const int units_y = same_panel ? 0 : CY * UPC;
   const int nunits = units_y + CX * UPC;
@@ -235,7 +236,41 @@ __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2
   const int fr = lane & 15, fk = lane >> 4;
   // first tile row / column of this wave in the panel (QUAD: its quadrant)
   const int ti0 = QUAD ? (wave >> 2) * PI : 0, tj0 = QUAD ? (wave & 3) * PJ : 0;
+  // Self-Gram of a 128 x 128 quadrant panel: only the 36 tiles on and above the diagonal are needed (gram_finalize
+  // mirrors the rest), but with one 4 x 2 quadrant per wave the four waves whose quadrants lie above the diagonal do all
+  // 8 of theirs and everybody waits for them.  Instead tile rows r and 7 - r (9 tiles together) go to the wave pair
+  // (2 r, 2 r + 1): wave 2 r takes (r, r .. r + 4), wave 2 r + 1 the other 3 - r tiles of row r and the r + 1 tiles of
+  // row 7 - r -- five or four tiles per wave instead of eight, still at most six fragment reads per k-step.
+  constexpr bool SYMQ = SYMS && QUAD && PI == 4 && PJ == 2;
+  constexpr bool sym = SYMQ;
+  const int sr = wave >> 1, sh = wave & 1;
+  auto sym_tile = [&](int t, int &ti, int &tj) {     // tile t of this wave in the symmetric assignment
+    if (sh == 0) { ti = sr; tj = sr + t; }
+    else if (t < 3 - sr) { ti = sr; tj = sr + 5 + t; }
+    else { ti = 7 - sr; tj = 7 - sr + (t - (3 - sr)); }
+  };
+  const int sym_cnt = sh == 0 ? 5 : 4;
+  auto mfma_phase_sym = [&]() {
+    if constexpr (SYMQ) {
+#pragma unroll 4
+      for (int ks = 0; ks < ROWS / 4; ++ks) {
+        const int row = ks * 4 + fk;
+        const R fa0 = ldsX[(sr * 16 + fr) * S + row];
+        const R fa1 = ldsX[((7 - sr) * 16 + fr) * S + row];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          if (t < sym_cnt) {
+            int ti, tj;
+            sym_tile(t, ti, tj);
+            const R fb = ldsX[(tj * 16 + fr) * S + row];
+            acc[t >> 1][t & 1] = M::run(ti == sr ? fa0 : fa1, fb, acc[t >> 1][t & 1]);
+          }
+        }
+      }
+    }
+  };
   auto mfma_phase = [&]() {
+    if (sym) { mfma_phase_sym(); return; }
     const int rbase = QUAD ? 0 : wave * (ROWS / 4);
 #pragma unroll 4
     for (int ks = 0; ks < (QUAD ? ROWS / 4 : ROWS / 16); ++ks) {
@@ -335,6 +370,20 @@ __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2
   if constexpr (QUAD) {
     // every wave owns its quadrant: straight from the accumulators to the partials
     R *outq = reinterpret_cast<R *>(a.partials) + (int64_t)panel * (VY * VX) * gridDim.x + blockIdx.x;
+    if (sym) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+        if (t < sym_cnt) {
+          int ti, tj;
+          sym_tile(t, ti, tj);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ii = ti * 16 + M::out_row(lane, r), jj = tj * 16 + (lane & 15);
+            outq[(int64_t)(ii * VX + jj) * gridDim.x] = acc[t >> 1][t & 1][r];
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PI; ++i)
 #pragma unroll
@@ -415,12 +464,12 @@ __global__ __launch_bounds__(256) void gram_finalize(const void *partials_, int 
 }
 
 // Resident workgroups per CU for one instantiation (registers + LDS), asked once.
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false, bool SYMS = false>
 static int gram_blocks_per_cu() {
   static int cached = 0;
   if (cached == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD>, QUAD ? 512 : 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD, SYMS>, QUAD ? 512 : 256, 0) != hipSuccess ||
         nb < 1)
       nb = 1;
     cached = nb > 8 ? 8 : nb;
@@ -441,7 +490,7 @@ static inline int pick_tiles(int v) {   // 16x16 tiles per panel side: 1, 2 or 4
   return 4;
 }
 
-template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false>
+template <int DT, int PI, int PJ, bool ALIGNED, int MODE, bool MULTI = false, bool QUAD = false, bool SYMS = false>
 static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, void *d_out) {
   using R = typename DType<DT>::R;
   Context &c = ctx();
@@ -449,14 +498,14 @@ static int gram_launch(GramArgs &a, int npi, int npj, int64_t my, int64_t mx, vo
   const int npanels = npi * npj;
   // the grid is sized to what is resident at once: every workgroup strides over the row
   // chunks, so a second, partially filled round of workgroups would only add a tail
-  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD>() / npanels;
+  int64_t nbx = (int64_t)c.num_cu * gram_blocks_per_cu<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD, SYMS>() / npanels;
   if (nbx < 1) nbx = 1;
   if (nbx > a.nchunks) nbx = a.nchunks;
   const size_t part_bytes = sizeof(R) * VY * VX;
   while (nbx > 1 && (size_t)nbx * npanels * part_bytes > kWorkspaceBytes) nbx /= 2;
   RLH_REQUIRE((size_t)nbx * npanels * part_bytes <= kWorkspaceBytes,
               "rlh_gram: %lld x %lld result exceeds the reduction workspace", (long long)my, (long long)mx);
-  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD>), dim3((unsigned)nbx, (unsigned)npanels), dim3(QUAD ? 512 : 256), 0,
+  hipLaunchKernelGGL((gram_kernel<DT, PI, PJ, ALIGNED, MODE, MULTI, QUAD, SYMS>), dim3((unsigned)nbx, (unsigned)npanels), dim3(QUAD ? 512 : 256), 0,
                      c.stream, a);
   RLH_HIP(hipGetLastError());
   const int total = (int)(my * mx);
@@ -801,6 +850,8 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   if (aligned && (vx > 64 || vy > 64) && vx > 32 && vy > 32 && env_quad()) {
     a.npj = (vx + 127) / 128;
     a.nchunks = (n + 256 / (int)sizeof(R) - 1) / (256 / (int)sizeof(R));
+    if (a.same && vx <= 128)      // one square panel of a self-Gram: the symmetric tile assignment
+      return gram_launch<DT, 4, 2, true, 0, false, true, true>(a, 1, 1, my, mx, d_out);
     return gram_launch<DT, 4, 2, true, 0, false, true>(a, (vy + 127) / 128, a.npj, my, mx, d_out);
   }
   // 33 .. 64 real columns on both sides: one 64 x 64 panel, 2 x 1 tiles per wave of a 512-thread workgroup
