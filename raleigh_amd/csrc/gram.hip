@@ -858,6 +858,7 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   if (aligned && vx > 32 && vy > 32 && vx <= 64 && vy <= 64 && env_quad()) {
     a.npj = 1;
     a.nchunks = (n + 512 / (int)sizeof(R) - 1) / (512 / (int)sizeof(R));
+    if (a.same) return gram_launch<DT, 2, 1, true, 0, false, true, true>(a, 1, 1, my, mx, d_out);   // staged once
     return gram_launch<DT, 2, 1, true, 0, false, true>(a, 1, 1, my, mx, d_out);
   }
   const int ROWS = (mode == 3 ? 2 : (mode == 4 ? 4 : 1)) * 512 / (int)sizeof(R);
