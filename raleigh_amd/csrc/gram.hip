@@ -708,17 +708,40 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
     __builtin_amdgcn_wave_barrier();
     compute();
   }
-  R *out = reinterpret_cast<R *>(a.partials) + t0;
+  // One partial per WORKGROUP: every wave leaves its accumulators in the (now idle) LDS, tile after tile as
+  // [lane][register], and the waves then sum the tiles in a fixed order, tile tt by wave tt mod WPG (a quarter of the
+  // scattered 8-byte partial writes and of gram_finalize's reads; the order of the sum does not depend on timing).
+  constexpr int SCR = PI * PJ * 256 * (int)sizeof(R);      // scratch per wave (may exceed its image: barrier first)
+  __syncthreads();
+  R *mine = reinterpret_cast<R *>(lds_all + (threadIdx.x >> 6) * SCR);
 #pragma unroll
   for (int i = 0; i < PI; ++i)
 #pragma unroll
-    for (int j = 0; j < PJ; ++j)
+    for (int j = 0; j < PJ; ++j) {
+      if (SELF && i > j) continue;
+      *reinterpret_cast<acc_t *>(mine + ((i * PJ + j) * 64 + lane) * 4) = acc[i][j];
+    }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  R *out = reinterpret_cast<R *>(a.partials) + blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < PI; ++i)
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      if (SELF && i > j) continue;
+      const int tt = i * PJ + j;
+      if (tt % WPG != wave) continue;          // (wave-uniform)
+      acc_t sum = acc_t{(R)0, (R)0, (R)0, (R)0};
+      for (int w = 0; w < WPG; ++w) {
+        const acc_t part = *reinterpret_cast<const acc_t *>(reinterpret_cast<const R *>(lds_all + w * SCR) + (tt * 64 + lane) * 4);
+        sum += part;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (SELF && i > j) continue;
         const int ii = i * 16 + M::out_row(lane, r), jj = j * 16 + (lane & 15);
-        out[(int64_t)(ii * NXC + jj) * G] = acc[i][j][r];
+        out[(int64_t)(ii * NXC + jj) * gridDim.x] = sum[r];
       }
+    }
 }
 
 // my <= 64, mx <= 64, every segment 16-byte aligned; a.xs / a.ys / a.nxs / a.nys describe the
@@ -737,12 +760,14 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   // at once (measured 6.3-6.7 TB/s at 4 waves per CU, 6.2 at 8, 4.8 at 2).
   const int wpg = gram_stream_waves(nyc + nxc);
   size_t lds = (size_t)wpg * (nyc + nxc) * TB;
+  const size_t scr = (size_t)wpg * ((self ? nxc : nyc) / 16) * (nxc / 16) * 256 * sizeof(R);   // the final reduction's scratch
+  if (lds < scr) lds = scr;
   if (lds < 84 * 1024) lds = 84 * 1024;          // more than half of the CU's 160 KB: one workgroup per CU
   const int64_t ntiles = (a.n + ROWS - 1) / ROWS;
   int64_t nbx = c.num_cu;
   if (nbx * wpg > ntiles) nbx = (ntiles + wpg - 1) / wpg;
   if (nbx < 1) nbx = 1;
-  const int64_t nparts = nbx * wpg;
+  const int64_t nparts = nbx;                    // one partial per workgroup
   int64_t nparts_alias = 0;
   const int VY = self ? nxc : nyc;
   RLH_REQUIRE((size_t)nparts * VY * nxc * sizeof(R) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
@@ -764,11 +789,12 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   if (a.xal >= 0 && nyc == 64 && nxc == 32) {
     // (the image and the launch are those of the 64-column Y window alone)
     lds = (size_t)8 * 64 * TB;
+    if (lds < (size_t)8 * 8 * 256 * sizeof(R)) lds = (size_t)8 * 8 * 256 * sizeof(R);
     if (lds < 84 * 1024) lds = 84 * 1024;
     nbx = c.num_cu;
     if (nbx * 8 > ntiles) nbx = (ntiles + 7) / 8;
     if (nbx < 1) nbx = 1;
-    nparts_alias = nbx * 8;
+    nparts_alias = nbx;
 #define RLH_GSA(NT_)                                                                                                   \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
