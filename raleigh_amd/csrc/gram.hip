@@ -844,11 +844,11 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
   if constexpr (!DType<DT>::cplx) {
     // real blocks, at most 32 columns on the X side and 64 on the Y side (and more than 8 on one of them): the
-    // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel; =2: the streaming kernel whatever the size)
+    // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel)
     const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    // (blocks that fit the Infinity Cache stay with the workgroup kernel: the streaming kernel writes one partial per
-    // wave -- 8 MB at 32 x 32 -- and measured 44 vs 39 us at n = 262144, 21 vs 14 us at n = 27000)
-    if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8) && (a.nt || stream > 1)) {
+    // (at every size: with one partial per workgroup it measures 15 vs 14 us at n = 27000, 37 vs 40 us at n = 262144,
+    // 91 vs 105 us at n = 10^6 against the workgroup kernel; the non-temporal hint stays a matter of size)
+    if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8)) {
       a.npj = 1;
       a.xal = -1;
       a.nxs = a.nys = 1;
@@ -943,7 +943,7 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
   a.nt = gram_nt(n * (mxt + myt) * es);
   if constexpr (!DType<DT>::cplx) {
     const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8) && (a.nt || stream > 1)) {
+    if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8)) {
       a.npj = 1;
       a.xal = -1;
       if (nx == 1 && mxt > 16 && mxt <= 32 && myt > 32)       // the X block is one of the Y window's blocks

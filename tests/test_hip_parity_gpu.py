@@ -86,7 +86,7 @@ def test_gram_streaming_kernel_shapes(key, n, mx, my, monkeypatch):
     than one tile, ragged widths (clamped columns), the 64-column left window, row counts that leave a partial
     tile; plain, self and stacked (windows made of blocks with DIFFERENT leading dimensions) requests."""
     from raleigh_amd.algebra.hip import Vectors
-    monkeypatch.setenv('RLH_GRAM_STREAM', '2')         # (by default only blocks beyond the Infinity Cache take this kernel)
+    monkeypatch.setenv('RLH_GRAM_STREAM', '1')         # (the default)
     rng = np.random.default_rng(n + 3 * mx + my)
     x, y = rnd((mx, n), key, rng), rnd((my, n), key, rng)
     X, Y = Vectors(x), Vectors(y)
@@ -118,7 +118,7 @@ def test_gram_streaming_kernel_shared_block(key, n, m, monkeypatch):
     """Stacked requests whose right block is also one of the left blocks ([X | Y]^H Y, [AX | X]^H X): the streaming
     kernel stages that block once and reads both fragment sides out of the same image."""
     from raleigh_amd.algebra.hip import Vectors
-    monkeypatch.setenv('RLH_GRAM_STREAM', '2')
+    monkeypatch.setenv('RLH_GRAM_STREAM', '1')
     rng = np.random.default_rng(n + m)
     x, y = rnd((m, n), key, rng), rnd((32, n), key, rng)
     X, Y = Vectors(x), Vectors(y)
