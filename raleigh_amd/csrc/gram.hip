@@ -550,7 +550,10 @@ constexpr int gram_stream_waves(int ncol) { return ncol <= 16 ? 16 : (ncol <= 32
 // XAL: the X window is a block that also sits in the Y window ([X | Y]^H Y, [AX | X]^H X of the solver's stacked
 // reductions), at columns a.xal .. (a multiple of 16): it is staged ONCE and the B fragments are read out of the Y
 // image (16 instead of 24 loads per tile; such calls took 0.92-1.0 ms where two distinct blocks stream in 0.77 ms).
-template <typename R, int TB, int NYC, int NXC, bool NT, bool XAL = false>
+// CPLX: the blocks are complex (NYC, NXC count the REAL-view columns: re and im of column c are the virtual columns 2 c,
+// 2 c + 1, as in the workgroup kernel; gram_finalize recombines conj(y) x).  A 16-byte piece then holds one complex128
+// row or two complex64 rows of a column; it is split on the way into the image (two 8-byte LDS writes).
+template <typename R, int TB, int NYC, int NXC, bool NT, bool XAL = false, bool CPLX = false>
 __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void gram_stream_kernel(GramArgs a) {
   using M = Mfma16<R>;
   using acc_t = typename M::acc_t;
@@ -559,8 +562,11 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
   constexpr int NP = TB / 16;                   // pieces per column and tile
   constexpr int ROWS = NP * RPU;                // rows per tile
   constexpr int NCOL = XAL ? NYC : NYC + NXC;   // staged columns: Y (NYC) then X (NXC = 16, 32 or 64; none if aliased)
-  constexpr int CPL = 64 / NP;                  // columns covered by one load instruction of the wave
-  constexpr int NL = NCOL / CPL;                // loads per lane and tile
+  constexpr int NC = CPLX ? 2 : 1;              // reals per element of the blocks
+  constexpr int NPT = NP * NC;                  // pieces per BLOCK column and tile (a complex column is two images)
+  constexpr int CPL = 64 / NPT;                 // block columns covered by one load instruction of the wave
+  constexpr int NL = NCOL / NC / CPL;           // loads per lane and tile
+  static_assert(!(CPLX && XAL) && NPT <= 64, "complex tiles");
   constexpr int KS = ROWS / 4;                  // MFMA k-steps per tile
   constexpr int SW = NP / 16;
   constexpr int PJ = NXC / 16, PI = SELF ? PJ : NYC / 16;
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
   char *lds = lds_all + (threadIdx.x >> 6) * (NCOL * TB);   // this wave's private image
   typedef R vec_t __attribute__((ext_vector_type(RPU)));
   const int lane = threadIdx.x & 63;
-  const int p = lane % NP, cl = lane / NP;
+  const int p = lane % NPT, cl = lane / NPT;
 
   // this lane's piece of staged column q * CPL + cl at row 0 (columns past a window repeat its last one: they
   // only feed entries that are never written out)
@@ -580,13 +586,13 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
   int tstep[NL];                                // rows a tile advances this lane's piece by: ROWS, or 0 past the window
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
-    const int sc = q * CPL + cl;
-    const bool isY = sc < NYC;
-    int c = isY ? sc : sc - NYC;
+    const int sc = q * CPL + cl;                // staged BLOCK column: Y window first, then X
+    const bool isY = sc < NYC / NC;
+    int c = isY ? sc : sc - NYC / NC;
     const int mc = isY ? a.my : a.mx;
     // staged columns past the window feed only entries that are never written out: their lanes re-read ONE
     // piece (row 0 of the window's last column, an L1 hit) instead of streaming a duplicate of that column
-    tstep[q] = c < mc ? ROWS : 0;
+    tstep[q] = c < mc ? ROWS * NC : 0;          // (in reals)
     c = c < mc ? c : mc - 1;
     const GramSeg *segs = isY ? a.ys : a.xs;
     const int ns = isY ? a.nys : a.nxs;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
 #pragma unroll
     for (int k = 1; k < kGramSegs; ++k)
       if (k < ns && c >= segs[k].c0) { bp = segs[k].p; ld = segs[k].ld; c0 = segs[k].c0; }
-    colp[q] = reinterpret_cast<const R *>(bp) + (int64_t)(c - c0) * ld + p * RPU;
+    colp[q] = reinterpret_cast<const R *>(bp) + (int64_t)(c - c0) * ld * NC + p * RPU;
   }
   vec_t regsA[NL], regsB[NL];
   auto load_tile = [&](int64_t tile, vec_t (&regs)[NL]) {
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
       const R *g = colp[q] + tile * tstep[q];
       vec_t v;
 #pragma unroll
-      for (int e = 0; e < RPU; ++e) v[e] = (row0 + p * RPU + e < a.n) ? g[e] : (R)0;
+      for (int e = 0; e < RPU; ++e) v[e] = (row0 + (p * RPU + e) / NC < a.n) ? g[e] : (R)0;
       regs[q] = v;
     }
   };
@@ -622,7 +628,19 @@ __global__ __launch_bounds__(64 * (XAL ? 8 : gram_stream_waves(NYC + NXC))) void
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
       const int sc = q * CPL + cl;
-      *reinterpret_cast<vec_t *>(lds + sc * TB + ((p ^ ((sc & 15) * SW)) << 4)) = regs[q];
+      if constexpr (!CPLX) {
+        *reinterpret_cast<vec_t *>(lds + sc * TB + ((p ^ ((sc & 15) * SW)) << 4)) = regs[q];
+      } else {
+        // piece p of the complex column: complex128 row p / complex64 rows 2 p, 2 p + 1 -> the 8-byte half p & 1 of
+        // slot p >> 1 of the re image (virtual column 2 sc) and of the im image (2 sc + 1)
+        typedef R half_t __attribute__((ext_vector_type(RPU / 2)));
+        half_t re, im;
+        if constexpr (RPU == 2) { re[0] = regs[q][0]; im[0] = regs[q][1]; }
+        else { re[0] = regs[q][0]; re[1] = regs[q][2]; im[0] = regs[q][1]; im[1] = regs[q][3]; }
+        const int v0 = 2 * sc, v1 = 2 * sc + 1, off8 = (p & 1) * 8;
+        *reinterpret_cast<half_t *>(lds + v0 * TB + (((p >> 1) ^ ((v0 & 15) * SW)) << 4) + off8) = re;
+        *reinterpret_cast<half_t *>(lds + v1 * TB + (((p >> 1) ^ ((v1 & 15) * SW)) << 4) + off8) = im;
+      }
     }
   };
   acc_t acc[PI][PJ];
@@ -753,8 +771,10 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   constexpr int TB = 256;
   constexpr int ROWS = TB / (int)sizeof(R);
   const bool self = a.same;
-  const int nxc = mx <= 16 ? 16 : (mx <= 32 ? 32 : 64);
-  const int nyc = self ? 0 : (my <= 16 && nxc < 64 ? 16 : (my <= 32 && nxc < 64 ? 32 : 64));
+  constexpr bool CPLX = DType<DT>::cplx;
+  const int64_t vmx = mx * (CPLX ? 2 : 1), vmy = my * (CPLX ? 2 : 1);       // real-view widths
+  const int nxc = vmx <= 16 ? 16 : (vmx <= 32 ? 32 : 64);
+  const int nyc = self ? 0 : (vmy <= 16 && nxc < 64 ? 16 : (vmy <= 32 && nxc < 64 ? 32 : 64));
   // One workgroup per CU of 4 waves (one per SIMD) where a tile is 12 KB or more, 8 / 16 waves for narrower
   // tiles: with two register sets in flight per wave more waves only widen the window of rows the chip works on
   // at once (measured 6.3-6.7 TB/s at 4 waves per CU, 6.2 at 8, 4.8 at 2).
@@ -775,18 +795,18 @@ static int gram_stream_launch(GramArgs &a, int64_t my, int64_t mx, void *d_out) 
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<R, TB, NYC_, NXC_, NT_>),         \
+      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_stream_kernel<R, TB, NYC_, NXC_, NT_, false, CPLX>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, NT_>), dim3((unsigned)nbx),                              \
+    hipLaunchKernelGGL((gram_stream_kernel<R, TB, NYC_, NXC_, NT_, false, CPLX>), dim3((unsigned)nbx),                 \
                        dim3(64 * gram_stream_waves(NYC_ + NXC_)), lds, c.stream, a);                                  \
   } while (0)
 #define RLH_GS(NYC_, NXC_)                                                                                             \
   do {                                                                                                                 \
     if (a.nt & 1) RLH_GS1(NYC_, NXC_, true); else RLH_GS1(NYC_, NXC_, false);                                          \
   } while (0)
-  if (a.xal >= 0 && nyc == 64 && nxc == 32) {
+  if (!CPLX && a.xal >= 0 && nyc == 64 && nxc == 32) {
     // (the image and the launch are those of the 64-column Y window alone)
     lds = (size_t)8 * 64 * TB;
     if (lds < (size_t)8 * 8 * 256 * sizeof(R)) lds = (size_t)8 * 8 * 256 * sizeof(R);
@@ -842,13 +862,13 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
   const int64_t es = dtype_size(DT);
   a.nt = gram_nt(n * (a.same ? mx : mx + my) * es);
   const bool aligned = aligned16(X, ldx, es) && aligned16(Y, ldy, es);
-  if constexpr (!DType<DT>::cplx) {
-    // real blocks, at most 32 columns on the X side and 64 on the Y side (and more than 8 on one of them): the
-    // wave-private streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel)
+  {
+    // windows of at most 64 real-view columns on either side (and more than 8 on one of them): the wave-private
+    // streaming kernel (RLH_GRAM_STREAM=0: the workgroup kernel)
     const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
     // (at every size: with one partial per workgroup it measures 15 vs 14 us at n = 27000, 37 vs 40 us at n = 262144,
     // 91 vs 105 us at n = 10^6 against the workgroup kernel; the non-temporal hint stays a matter of size)
-    if (stream && aligned && mx <= 64 && my <= 64 && (mx > 8 || my > 8)) {
+    if (stream && aligned && vx <= 64 && vy <= 64 && (vx > 8 || vy > 8)) {
       a.npj = 1;
       a.xal = -1;
       a.nxs = a.nys = 1;
@@ -941,12 +961,12 @@ static int gram_multi_impl(int64_t n, int nx, const void *const *X, const int64_
   a.X = X[0]; a.Y = Y[0]; a.ldx = ldx[0]; a.ldy = ldy[0]; a.n = n; a.mx = (int)mxt; a.my = (int)myt;
   a.same = 0; a.npj = npj; a.partials = c.work;
   a.nt = gram_nt(n * (mxt + myt) * es);
-  if constexpr (!DType<DT>::cplx) {
+  {
     const int stream = getenv("RLH_GRAM_STREAM") ? atoi(getenv("RLH_GRAM_STREAM")) : 1;
-    if (stream && aligned && mxt <= 64 && myt <= 64 && (mxt > 8 || myt > 8)) {
+    if (stream && aligned && vx <= 64 && vy <= 64 && (vx > 8 || vy > 8)) {
       a.npj = 1;
       a.xal = -1;
-      if (nx == 1 && mxt > 16 && mxt <= 32 && myt > 32)       // the X block is one of the Y window's blocks
+      if (!DType<DT>::cplx && nx == 1 && mxt > 16 && mxt <= 32 && myt > 32)   // the X block is one of the Y window's blocks
         for (int k2 = 0; k2 < ny; ++k2)
           if (Y[k2] == X[0] && ldy[k2] == ldx[0] && my[k2] == mx[0] && a.ys[k2].c0 % 16 == 0) a.xal = a.ys[k2].c0;
       return gram_stream_launch<DT>(a, myt, mxt, d_out);
