@@ -1,0 +1,326 @@
+"""Lower-rank approximation A - e a ~ L R of a dense data matrix on MI355X, its update with new
+rows and the incremental variant.
+
+Counterpart of the reference's LowerRankApproximation (raleigh/interfaces/lra.py:19-149 compute,
+:157-379 update, :381-425 icompute, :427-455 accessors), written from the algebra for this
+repository's device Vectors / Matrix.  Everything of the size of the data stays in HBM; the host
+sees k x k matrices only.
+
+update(), with the existing approximation A0 - e0 a0 ~ L0 R0 (n0 rows) and n1 new rows A1:
+
+  1. the mean of all n = n0 + n1 rows is a = (n0 a0 + n1 a1) / n, so
+         A0 - e0 a = L0 R0 + e0 d,   d = a0 - a = c R0 + d_perp
+     -> L0 += e0 c, and the pair (|d_perp| e0, d_perp / |d_perp|) becomes one more component;
+  2. C = (A1 - e1 a) R0^H -- what the existing components describe of the new rows -- is ONE fused
+     dense product (rlh_dense_apply_r1);
+  3. the rest, E = (A1 - e1 a)(I - R0^H R0), is never formed: its leading singular triplets come from
+     block JCG on the deflated normal operator (pca._OperatorSVD with `deflate`), i.e. two GEMMs plus
+     thin block algebra per iteration.  (The reference overwrites a copy of A1 with E: one more matrix
+     in memory and two more passes over it);
+  4. stacked:  [A0; A1] - e a ~ [[L0, 0], [C, L1]] [R0; R1]; a k x k eigenproblem turns this into
+     orthogonal columns times orthonormal rows in descending order, and the tail is cut to the
+     requested rank or tolerance.
+"""
+
+import math
+
+import numpy
+import scipy.linalg as sla
+
+from ..algebra.dense_matrix import AMatrix
+from ..core.solver import Options
+from .pca import PartialSVD, _SingularValueCriteria, _FrobeniusStopping, _project_out
+
+
+def _as_matrix(A, arch):
+    if hasattr(A, 'as_operator'):
+        return A
+    if not isinstance(A, numpy.ndarray) or not A.flags['C_CONTIGUOUS']:
+        raise ValueError('matrix must be C_CONTIGUOUS')
+    return AMatrix(A, arch=arch)
+
+
+class LowerRankApproximation:
+    """left() (rows x k, orthogonal columns in descending order of norm), right() (k x columns,
+    orthonormal rows) and mean() (1 x columns, or None without the shift) such that
+    left() @ right() ~ A - e mean()."""
+
+    def __init__(self, have=None, arch='hip'):
+        self.__left_v = self.__right_v = self.__mean_v = None
+        self.__rank = 0
+        self.__tol = 0.0
+        self.__svtol = 1e-3
+        self.__norm = 'f'
+        self.iterations = 0
+        self.operator_time = 0.0
+        self.sigma = None
+        if have is not None:
+            mean, left, right = have
+            from ..algebra.hip import Vectors
+            right = numpy.ascontiguousarray(right)
+            left = numpy.ascontiguousarray(numpy.asarray(left, dtype=right.dtype).T)
+            if left.shape[0] != right.shape[0]:
+                raise ValueError('have: trans and comps disagree on the number of components')
+            self.__left_v = Vectors(left)
+            self.__right_v = Vectors(right)
+            if mean is not None:
+                mean = numpy.ascontiguousarray(numpy.reshape(numpy.asarray(mean, dtype=right.dtype), (1, right.shape[1])))
+                self.__mean_v = Vectors(mean)
+            self.__rank = right.shape[0]
+
+    # ------------------------------------------------------------------ compute
+    def compute(self, matrix, opt=None, rank=-1, tol=0, norm='f', max_rank=-1, svtol=1e-3, shift=False,
+                verb=0, _mean=None, _deflate=None, _frob2=None):
+        """Leading singular triplets of the (optionally mean-shifted) matrix: `rank` of them, or as many as
+        bring the Frobenius norm of the remainder below tol |A_s|_F (tol > 0) or -tol (tol < 0)
+        (lra.py:109-149 -> partial_svd.py:52-133)."""
+        if norm != 'f':
+            raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
+        if opt is None:
+            opt = Options()
+        m, n = matrix.shape()
+        psvd = PartialSVD(matrix, shift=shift, mean=_mean, deflate=_deflate)
+        user_bs, user_cc, user_sc = opt.block_size, opt.convergence_criteria, opt.stopping_criteria
+        if user_bs < 1 and (rank < 0 or rank > 100):
+            opt.block_size = 128
+        if user_cc is None:
+            opt.convergence_criteria = _SingularValueCriteria(svtol)
+        if user_sc is None and rank < 0:
+            if tol == 0:
+                raise ValueError('either the rank or tol must be given (interactive stopping is not available)')
+            if _frob2 is None:
+                _frob2 = matrix.frobenius2()
+                if shift:       # |A_s|_F^2 = sum_i |a_i|^2 - m |mean|^2
+                    aves = psvd.op_svd().aves
+                    _frob2 -= m * float(numpy.abs(aves.dots(aves))[0])
+            opt.stopping_criteria = _FrobeniusStopping(_frob2, tol, max_rank)
+        try:
+            psvd.compute(opt, rank)
+        finally:
+            opt.block_size, opt.convergence_criteria, opt.stopping_criteria = user_bs, user_cc, user_sc
+        if psvd.status < 0:
+            raise RuntimeError('block JCG failed with status %d' % psvd.status)
+        left, right = psvd.left_v(), psvd.right_v()
+        left.scale(psvd.sigma, multiply=True)
+        k = left.nvec()
+        if rank > 0:
+            k = min(k, rank)
+        elif max_rank > 0:
+            k = min(k, max_rank)
+        left.select(k)
+        right.select(k)
+        self.__left_v, self.__right_v = left, right
+        self.__mean_v = psvd.mean_v() if shift else None
+        self.__rank, self.__tol, self.__svtol, self.__norm = k, tol, svtol, norm
+        self.iterations = psvd.iterations
+        self.operator_time = psvd.op_svd().time
+        self.sigma = psvd.sigma[:k]
+
+    # ------------------------------------------------------------------ update
+    def update(self, matrix, opt=None, rank=-1, max_rank=-1, tol=None, norm=None, svtol=None, verb=0):
+        """The approximation of numpy.concatenate((A0, A1)) from that of A0 held here and the new rows
+        `matrix` = A1 (lra.py:157-379); steps in the module docstring."""
+        if self.__rank == 0:
+            raise RuntimeError('no existing LRA data to update')
+        tol = self.__tol if tol is None else tol
+        norm = self.__norm if norm is None else norm
+        svtol = self.__svtol if svtol is None else svtol
+        if norm != 'f':
+            raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
+        if tol == 0.0 and rank < 1:
+            rank = self.__rank
+        left, right = self.__left_v, self.__right_v
+        dtype = right.data_type()
+        if matrix.data_type() != dtype:
+            raise ValueError('incompatible matrix type passed to update')
+        if numpy.dtype(dtype).kind == 'c':
+            raise ValueError('update: real data only')
+        n1, ncol = matrix.shape()
+        if ncol != right.dimension():
+            raise ValueError('update: the new rows have %d columns, the components %d' % (ncol, right.dimension()))
+        if n1 < 1:
+            return
+        op = matrix.as_operator()
+        n0 = left.dimension()
+        n = n0 + n1
+        shift = self.__mean_v is not None
+
+        left, right = _orthogonal_times_orthonormal(left, right)
+        sigma0 = math.sqrt(float(numpy.abs(left.dots(left))[0])) if left.nvec() > 0 else 0.0
+
+        row_norms2 = numpy.abs(matrix.dots())
+        frob2 = float(numpy.sum(row_norms2))
+        mean_v = None
+        if shift:
+            # a1 = A1^T e1 / n1 ;  a = (n0 a0 + n1 a1) / n ;  d = a0 - a
+            e1 = op.new_vectors(n1, 1)
+            e1.fill(numpy.ones((1, n1), dtype=dtype))
+            a1 = op.new_vectors(ncol, 1)
+            op.apply(e1, a1, transp=True)
+            mean_v = op.new_vectors(ncol, 1)
+            mean_v.lincomb(n0 / n, self.__mean_v, 1.0 / n, a1)
+            d = op.new_vectors(ncol, 1)
+            d.lincomb(1.0, self.__mean_v, -1.0, mean_v)
+            c = d.dot(right)                                    # (k, 1): d = c^T R0 + d_perp
+            d.add(right, -1.0, c)
+            _project_out(d, right)
+            e0 = left.new_vectors(1)
+            e0.fill(numpy.ones((1, n0), dtype=dtype))
+            left.add(e0, 1.0, numpy.ascontiguousarray(c.T))     # L0 += e0 c
+            s = math.sqrt(float(numpy.abs(d.dots(d))[0]))
+            if s > numpy.finfo(dtype).eps * max(sigma0, numpy.finfo(dtype).tiny):
+                d.scale(numpy.full((1,), s, dtype=dtype))
+                e0.scale(numpy.full((1,), s, dtype=dtype), multiply=True)
+                left.append(e0)
+                right.append(d)
+            # |A1 - e1 a|_F^2 = sum |row|^2 - 2 n1 a1.a + n1 |a|^2   (a1 still holds n1 times the mean of A1)
+            frob2 += -2.0 * float(numpy.real(a1.dot(mean_v))[0, 0]) + n1 * float(numpy.abs(mean_v.dots(mean_v))[0])
+            frob2 = max(frob2, 0.0)
+        k0 = right.nvec()
+
+        # C = A1_s R0^H: what the components in hand describe of the new rows (R0 real: no conjugation)
+        lra = LowerRankApproximation()
+        probe = PartialSVD(matrix, shift=shift, mean=mean_v) if shift else None
+        C = op.new_vectors(n1, k0)
+        if shift:
+            probe.op_svd().forward(right, C)
+        else:
+            op.apply(right, C)
+        rest2 = max(frob2 - float(numpy.sum(numpy.abs(C.dots(C)))), 0.0)     # |E|_F^2
+
+        if not shift:
+            raise ValueError('update without the mean shift is not available')
+        if rest2 <= (numpy.finfo(dtype).eps * 16) ** 2 * frob2 or (rank < 0 and math.sqrt(rest2) <= tol * math.sqrt(frob2) / 4):
+            pass        # the components in hand already describe the new rows: nothing to add
+        elif rank < 0:
+            urank = max_rank * n1 // n if max_rank > 0 else -1
+            lra.compute(matrix, opt, tol=-tol * math.sqrt(frob2), max_rank=urank, svtol=svtol, shift=True,
+                        verb=verb, _mean=mean_v, _deflate=(right, C), _frob2=rest2)
+        else:
+            urank = max(1, rank * n1 // n)
+            urank = min(urank, max(1, min(n1, ncol) - k0))
+            if verb > 0:
+                print('computing new %d components...' % urank)
+            lra.compute(matrix, opt, rank=urank, svtol=svtol, shift=True, verb=verb, _mean=mean_v,
+                        _deflate=(right, C))
+        new = 0 if lra.right_v() is None else lra.right_v().nvec()
+
+        # [[L0, 0], [C, L1]] and [R0; R1]
+        left.append(C, axis=1)
+        if new > 0:
+            L1, R1 = lra.left_v().clone(), lra.right_v()     # (clone: the selected window only)
+            _project_out(R1, right)
+            top = left.new_vectors(new, n0)
+            top.zero()
+            top.append(L1, axis=1)
+            left.append(top)
+            right.append(R1)
+        left, right = _orthogonal_times_orthonormal(left, right)
+
+        ncomp = right.nvec()
+        if rank < 0:
+            r = numpy.abs(left.dots(left))
+            eps = math.sqrt(float(numpy.sum(r))) * tol / 4
+            tail, drop = 0.0, 0
+            while drop + 1 < ncomp:
+                tail += float(r[ncomp - 1 - drop])
+                if math.sqrt(tail) > eps:
+                    break
+                drop += 1
+            if drop > 0 and verb > 0:
+                print('discarding %d components out of %d' % (drop, ncomp))
+            ncomp -= drop
+            if max_rank > 0:
+                ncomp = min(ncomp, max_rank)
+        else:
+            ncomp = min(ncomp, rank)
+        left.select(ncomp)
+        right.select(ncomp)
+        self.__left_v, self.__right_v, self.__mean_v = left, right, mean_v
+        self.__rank, self.__tol, self.__svtol, self.__norm = ncomp, tol, svtol, norm
+        self.iterations += lra.iterations
+        self.operator_time += lra.operator_time
+        self.sigma = numpy.sqrt(numpy.abs(left.dots(left)))
+
+    # ------------------------------------------------------------------ incremental
+    def icompute(self, matrix, batch_size, opt=None, rank=-1, tol=0, norm='f', max_rank=-1, svtol=1e-3,
+                 shift=False, arch='hip', verb=0):
+        """compute() on the first `batch_size` rows of the host array `matrix`, update() with every further
+        batch (lra.py:381-425): one batch of the data in HBM at a time."""
+        rows = matrix.shape[0]
+        batch_size = max(1, min(batch_size, rows))
+        first, batch = 0, 0
+        iterations = 0
+        if self.__rank == 0:
+            if verb > 0:
+                print('processing batch %d of size %d' % (batch, batch_size))
+            self.compute(_as_matrix(matrix[:batch_size, :], arch), opt=opt, rank=rank, tol=tol, norm=norm,
+                         max_rank=max_rank, svtol=svtol, shift=shift, verb=verb)
+            iterations = self.iterations
+            first, batch = batch_size, 1
+        while first < rows:
+            last = min(rows, first + batch_size)
+            if verb > 0:
+                print('processing batch %d of size %d' % (batch, last - first))
+            self.iterations = 0
+            self.update(_as_matrix(matrix[first:last, :], arch), opt=opt, rank=rank, tol=tol, norm=norm,
+                        max_rank=max_rank, svtol=svtol, verb=verb)
+            iterations += self.iterations
+            first, batch = last, batch + 1
+        self.iterations = iterations
+
+    # ------------------------------------------------------------------ accessors
+    def mean(self):
+        return None if self.__mean_v is None else self.__mean_v.data()
+
+    def left(self):
+        return None if self.__left_v is None else self.__left_v.data().T
+
+    def right(self):
+        return None if self.__right_v is None else self.__right_v.data()
+
+    def mean_v(self):
+        return self.__mean_v
+
+    def left_v(self):
+        return self.__left_v
+
+    def right_v(self):
+        return self.__right_v
+
+
+def _orthogonal_times_orthonormal(left, right):
+    """Rewrites the product sum_i left_i right_i (left_i: vectors of the row dimension, right_i: of the
+    column dimension) with orthonormal `right` and mutually orthogonal `left` in descending order of norm;
+    returns the new pair.  (The job of lra.py:213-227, 311-326 and `_lra_ortho`, done with two Gram
+    matrices, two k x k eigenproblems and two block updates, whatever the conditioning of `right`.)
+
+    H = R R^H = U M U^H:  R = (U M^1/2) Q with orthonormal Q = M^-1/2 U^H R;  L R = (L U M^1/2) Q; then
+    (L U M^1/2)^H (L U M^1/2) = W D W^H gives L' = L U M^1/2 W, R' = W^H Q.  Directions of `right` with
+    no weight (M below rounding) carry nothing and are dropped."""
+    k = right.nvec()
+    if k < 1:
+        return left, right
+    dtype = right.data_type()
+    wide = numpy.complex128 if numpy.dtype(dtype).kind == 'c' else numpy.float64
+    H = numpy.conj(right.dot(right)).astype(wide)
+    H = (H + H.conj().T) / 2
+    mu, U = sla.eigh(H)
+    keep = mu > numpy.finfo(dtype).eps * k * max(mu[-1], 0.0)
+    if not numpy.any(keep):
+        keep[-1] = True
+    mu, U = mu[keep], U[:, keep]
+    G = left.dot(left).astype(wide)
+    G = (G + G.conj().T) / 2
+    B = U * numpy.sqrt(mu)[None, :]
+    lam, W = sla.eigh(B.conj().T @ G @ B)
+    order = numpy.argsort(-lam)
+    W = W[:, order]
+    t_left = B @ W                                               # L' = L (U M^1/2 W)
+    t_right = numpy.conj(U / numpy.sqrt(mu)[None, :]) @ numpy.conj(W)   # R'_j = sum_i (W^H M^-1/2 U^H)[j, i] R_i
+    kk = t_left.shape[1]
+    new_left = left.new_vectors(kk)
+    new_right = right.new_vectors(kk)
+    left.multiply(numpy.ascontiguousarray(t_left.astype(dtype)), new_left)
+    right.multiply(numpy.ascontiguousarray(t_right.astype(dtype)), new_right)
+    return new_left, new_right

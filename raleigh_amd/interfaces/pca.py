@@ -8,8 +8,9 @@ Vectors / Matrix: the hot loop is the pair of dense products of ``_OperatorSVD.a
 
 Supported: a fixed number of components (``npc``) and the Frobenius-norm tolerance
 (``tol`` with ``norm='f'``), with the mean shift; samples >= features or the transposed
-case.  Out of scope: PCA update / incremental PCA, interactive stopping,
-the 's' and 'm' norms.
+case; the update of an existing approximation with new samples (``have``) and incremental
+PCA (``batch_size``), see lra.py.  Out of scope: interactive stopping, the
+'s' and 'm' norms.
 """
 
 import math
@@ -20,6 +21,11 @@ import numpy.linalg as nla
 
 from ..algebra.dense_matrix import AMatrix
 from ..core.solver import Problem, Solver, Options
+
+
+def _project_out(x, basis):
+    """x -= basis (basis^H x) for an orthonormal basis: one Gram and one block update."""
+    x.add(basis, -1.0, x.dot(basis))
 
 
 class _OperatorSVD:
@@ -38,27 +44,39 @@ class _OperatorSVD:
     extra pass over the M x k or N x k block (the reference makes two dot + add passes per product).
     Other operators (row-sharded data) take the same steps with dot / add calls."""
 
-    def __init__(self, matrix, v, transp=False, shift=False):
+    def __init__(self, matrix, v, transp=False, shift=False, mean=None, deflate=None):
         self.op = matrix.as_operator()
         self.gpu = matrix.gpu()
         self.transp = transp
         self.shift = shift
         self.time = 0
+        # `mean`: a given row a (one vector of dimension N) instead of the column means of A -- then
+        # e^T (A - e a) != 0 and both products carry their rank-one term.  `deflate` = (R, C): R an
+        # orthonormal basis (vectors of dimension N) and C = A_s R^H (vectors of dimension M); the operator
+        # becomes that of E = A_s (I - R^H R), the part of the data an existing set of components R does
+        # not describe (lra.py: update).  Both need the fused products.
+        self.own_mean = mean is None
+        self.deflate = deflate
         m, n = self.op.shape()
         # vectors are created by the OPERATOR so that a row-sharded matrix can hand out
         # sharded vectors for its row dimension and replicated ones for its column dimension
         self.w = self.op.new_vectors(n if transp else m, 0)
         self._fused = hasattr(self.op, 'apply_r1')
         self._coef = None
+        if (mean is not None or deflate is not None) and not (self._fused and shift):
+            raise ValueError('a given mean / a deflated operator need a Matrix with apply_r1 and shift')
         if shift:
             dt = self.op.data_type()
             self.ones = self.op.new_vectors(m, 1)
             self.ones.fill(numpy.ones((1, m), dtype=dt))
-            self.aves = self.op.new_vectors(n, 1)
-            self.op.apply(self.ones, self.aves, transp=True)     # A^H e = M conj(a)
-            self.aves.scale(numpy.full((1,), m, dtype=dt))
-            if self.aves.is_complex():
-                self.aves.conjugate()                            # a itself
+            if mean is not None:
+                self.aves = mean
+            else:
+                self.aves = self.op.new_vectors(n, 1)
+                self.op.apply(self.ones, self.aves, transp=True)     # A^H e = M conj(a)
+                self.aves.scale(numpy.full((1,), m, dtype=dt))
+                if self.aves.is_complex():
+                    self.aves.conjugate()                            # a itself
             # <x, conj(a)> = a^T x: the one-column Gram conjugates its second argument
             self.aves_c = self.aves
             if self.aves.is_complex():
@@ -71,6 +89,20 @@ class _OperatorSVD:
         if self._coef is None or self._coef.nbytes < 2 * k * es:
             self._coef = DeviceBuffer(2 * max(k, 16) * es, zero=False)
         return self._coef.ptr + slot * k * es
+
+    def forward(self, x, z):
+        """z = A_s x for vectors x of dimension N (fused products only)."""
+        from ..algebra.hip.matrix import coefficients_into
+        c0 = self._coefficients(x.nvec(), 0)
+        coefficients_into(c0, x, self.aves_c)                             # c = a^T x
+        self.op.apply_r1(x, z, False, None, c0)                           # z = A x - e c^T
+
+    def backward(self, z, y):
+        """y = A_s^T z for vectors z of dimension M (fused products only)."""
+        from ..algebra.hip.matrix import coefficients_into
+        c1 = self._coefficients(z.nvec(), 1)
+        coefficients_into(c1, z, self.ones)                               # s = e^T z
+        self.op.apply_r1(z, y, True, self.aves, c1)                       # y = A^T z - a s^T
 
     def apply(self, x, y):
         m, n = self.op.shape()
@@ -89,12 +121,21 @@ class _OperatorSVD:
             if self.transp:
                 coefficients_into(c0, x, self.ones)                       # s = e^T x
                 self.op.apply_r1(x, z, True, self.aves, c0)               # z = A^T x - a s^T
+                if self.deflate is not None:
+                    _project_out(z, self.deflate[0])                      # z = (I - R^H R) z
                 coefficients_into(c1, z, self.aves_c)                     # t = a^T z
                 self.op.apply_r1(z, y, False, None, c1)                   # y = A z - e t^T
             else:
                 coefficients_into(c0, x, self.aves_c)                     # c = a^T x
                 self.op.apply_r1(x, z, False, None, c0)                   # z = A x - e c^T
-                self.op.apply(z, y, transp=True)                          # y = A^T z
+                if self.deflate is not None:                              # z = A_s (I - R^H R) x = A_s x - C (R x)
+                    z.add(self.deflate[1], -1.0, x.dot(self.deflate[0]))
+                if self.own_mean:
+                    self.op.apply(z, y, transp=True)                      # y = A^T z (e^T z = 0)
+                else:
+                    self.backward(z, y)
+                if self.deflate is not None:
+                    _project_out(y, self.deflate[0])
         elif self.transp:
             self.op.apply(x, z, transp=True)
             z.add(self.aves, -1.0, x.dot(self.ones))                      # - a (e^T x)
@@ -151,12 +192,12 @@ class PartialSVD:
     """Leading singular triplets of A (optionally mean-shifted) via block JCG on the
     normal operator (partial_svd.py:19-160)."""
 
-    def __init__(self, matrix, shift=False):
+    def __init__(self, matrix, shift=False, mean=None, deflate=None):
         self.__op = matrix.as_operator()
         m, n = matrix.shape()
         self.__transp = m < n
         self.__v = self.__op.new_vectors(m if self.__transp else n)
-        self.__opsvd = _OperatorSVD(matrix, self.__v, self.__transp, shift)
+        self.__opsvd = _OperatorSVD(matrix, self.__v, self.__transp, shift, mean, deflate)
         self.__shift = shift
         self.sigma = None
         self.iterations = -1
@@ -183,12 +224,22 @@ class PartialSVD:
             self.sigma = numpy.zeros((0,), dtype=v.data_type())
             self.u, self.v = u, v
             return
-        op.apply(v, u, transp)
-        if self.__shift:            # u = A_s v (or A_s^T v)
-            if not transp:
-                u.add(opSVD.ones, -1, v.dot(opSVD.aves))
+        if opSVD.deflate is not None or not opSVD.own_mean:
+            if not transp:          # v spans a subspace of range(I - R^H R) up to rounding: make it exact
+                if opSVD.deflate is not None:
+                    _project_out(v, opSVD.deflate[0])
+                opSVD.forward(v, u)
             else:
-                u.add(opSVD.aves, -1, v.dot(opSVD.ones))
+                opSVD.backward(v, u)
+                if opSVD.deflate is not None:
+                    _project_out(u, opSVD.deflate[0])
+        else:
+            op.apply(v, u, transp)
+            if self.__shift:            # u = A_s v (or A_s^T v)
+                if not transp:
+                    u.add(opSVD.ones, -1, v.dot(opSVD.aves))
+                else:
+                    u.add(opSVD.aves, -1, v.dot(opSVD.ones))
         sigma = numpy.sqrt(abs(u.dots(u)))
         u.scale(sigma)
         ind = numpy.argsort(-sigma)
@@ -209,56 +260,37 @@ class PartialSVD:
         return self.__opsvd.mean_v()
 
 
-def pca(A, npc=-1, tol=0, verb=0, arch='hip', norm='f', mpc=-1, svtol=1e-3, opt=None):
+def pca(A, npc=-1, tol=0, have=None, batch_size=None, verb=0, arch='hip', norm='f', mpc=-1, svtol=1e-3, opt=None):
     '''PCA of the rows of A: returns (mean (1, n), trans (m, k), comps (k, n)) with
     trans @ comps ~ A - e mean, comps rows orthonormal, columns of trans in descending
-    order of norm (raleigh/interfaces/pca.py:16-91).
+    order of norm (raleigh/interfaces/pca.py:16-164).
 
     npc : number of components, or negative to use `tol`;
     tol : with npc < 0, stop when ||A_s - L R||_F <= tol ||A_s||_F (tol > 0) or <= -tol;
+    have : (mean0, trans0, comps0) of data A0 seen earlier -- the result then describes
+        numpy.concatenate((A0, A)); with neither npc nor tol, as many components as comps0 has;
+    batch_size : incremental PCA, `batch_size` rows of A in HBM at a time;
     mpc : cap on the number of components when tol is used;
     svtol : singular value tolerance relative to the largest one.'''
+    from .lra import LowerRankApproximation, _as_matrix
     if norm != 'f':
         raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
     if opt is None:
         opt = Options()
-    if hasattr(A, 'as_operator'):       # an AMatrix-like wrap, e.g. dist.ShardedAMatrix (rows sharded)
-        matrix = A
+    lra = LowerRankApproximation(have)
+    if batch_size is None:
+        matrix = _as_matrix(A, arch)        # an ndarray, or an AMatrix-like wrap, e.g. dist.ShardedAMatrix
+        if have is None:
+            lra.compute(matrix, opt=opt, rank=npc, tol=tol, norm=norm, max_rank=mpc, svtol=svtol, shift=True, verb=verb)
+        else:
+            lra.update(matrix, opt=opt, rank=npc, tol=tol, norm=norm, max_rank=mpc, svtol=svtol, verb=verb)
     else:
         if not isinstance(A, numpy.ndarray) or not A.flags['C_CONTIGUOUS']:
             raise ValueError('matrix must be C_CONTIGUOUS')
-        matrix = AMatrix(A, arch=arch)
-    m, n = matrix.shape()
-    psvd = PartialSVD(matrix, shift=True)
-    user_bs, user_cc, user_sc = opt.block_size, opt.convergence_criteria, opt.stopping_criteria
-    if user_bs < 1 and (npc < 0 or npc > 100):
-        opt.block_size = 128
-    if user_cc is None:
-        opt.convergence_criteria = _SingularValueCriteria(svtol)
-    if user_sc is None and npc < 0:
-        if tol == 0:
-            raise ValueError('either npc or tol must be given (interactive stopping is not available)')
-        opSVD = psvd.op_svd()
-        # ||A_s||_F^2 = sum_i ||a_i||^2 - m ||mean||^2
-        frob2 = matrix.frobenius2() - m * float(numpy.abs(opSVD.aves.dots(opSVD.aves))[0])
-        opt.stopping_criteria = _FrobeniusStopping(frob2, tol, mpc)
-    try:
-        psvd.compute(opt, npc)
-    finally:
-        opt.block_size, opt.convergence_criteria, opt.stopping_criteria = user_bs, user_cc, user_sc
-    if psvd.status < 0:
-        raise RuntimeError('block JCG failed with status %d' % psvd.status)
-    left, right = psvd.left_v(), psvd.right_v()
-    left.scale(psvd.sigma, multiply=True)
-    k = left.nvec()
-    if npc > 0:
-        k = min(k, npc)
-    elif mpc > 0:
-        k = min(k, mpc)
-    left.select(k)
-    right.select(k)
-    pca.last = {'iterations': psvd.iterations, 'operator_time': psvd.op_svd().time, 'sigma': psvd.sigma[:k]}
-    return psvd.mean_v().data(), left.data().T, right.data()
+        lra.icompute(A, batch_size, opt=opt, rank=npc, tol=tol, norm=norm, max_rank=mpc, svtol=svtol, shift=True,
+                     verb=verb, arch=arch)
+    pca.last = {'iterations': lra.iterations, 'operator_time': lra.operator_time, 'sigma': lra.sigma}
+    return lra.mean(), lra.left(), lra.right()
 
 
 def pca_error(data, mean, trans, comps):

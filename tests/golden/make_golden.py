@@ -278,7 +278,41 @@ def pca_known_answers():
                                   'sigma_exact': exact.tolist()}}
 
 
+def pca_update_known_answers():
+    """pca(have=...) and pca(batch_size=...) of the reference (interfaces/pca.py:142-164 -> lra.py:157-425) on
+    generate(600, 400, 200): errors of the approximation of ALL rows, number of components, and how far the
+    reference's own result is from orthonormal rows / the exact mean."""
+    from raleigh.examples.pca.generate_matrix import generate
+    from raleigh.interfaces.pca import pca, pca_error
+    np.random.seed(1)
+    A, sigma, u, v = generate(600, 400, 200, pca=True)
+    res = {}
+
+    def record(name, mean, trans, comps):
+        em, ef = pca_error(A, mean, trans, comps)
+        res[name] = {'em': float(em), 'ef': float(ef), 'ncomp': int(comps.shape[0]),
+                     'ortho': float(np.abs(comps @ comps.T - np.eye(comps.shape[0])).max()),
+                     'mean_err': float(np.abs(mean - A.mean(axis=0)).max()),
+                     'sigma': np.linalg.norm(trans, axis=0).astype(np.float64)[:10].tolist()}
+    A0, A1 = A[:480], A[480:]
+    mean, trans, comps = pca(A0, tol=0.05)
+    record('pca_600x400_update_tol', *pca(A1, have=(mean, trans, comps)))
+    mean, trans, comps = pca(A0, npc=30)
+    record('pca_600x400_update_npc30', *pca(A1, have=(mean, trans, comps)))
+    record('pca_600x400_incremental_tol', *pca(A, batch_size=200, tol=0.05))
+    record('pca_600x400_incremental_npc30', *pca(A, batch_size=200, npc=30))
+    return res
+
+
 def main():
+    if '--pca-update-only' in sys.argv:       # adds the update / incremental entries to the existing file
+        path = os.path.join(HERE, 'known_answers.json')
+        known = json.load(open(path))
+        known.update(pca_update_known_answers())
+        with open(path, 'w') as f:
+            json.dump(known, f, indent=1)
+        print(json.dumps({k: v for k, v in known.items() if 'update' in k or 'incremental' in k}, indent=1))
+        return
     shapes = [(5, 257), (16, 192)]
     for key in DTYPES:
         for (m, n) in shapes:
@@ -302,6 +336,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'sparse.npz'), **sparse_apply())
     known = solver_known_answers()
     known.update(pca_known_answers())
+    known.update(pca_update_known_answers())
     known['_meta'] = {'numpy': np.__version__, 'have_mkl': HAVE_MKL,
                       'reference': 'evgueni-ovtchinnikov/raleigh v1.3.5 @ 2024-12-20'}
     with open(os.path.join(HERE, 'known_answers.json'), 'w') as f:

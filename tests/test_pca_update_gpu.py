@@ -1,0 +1,55 @@
+"""GPU tier: PCA update and incremental PCA through librlhip.so (fused dense products of the deflated operator,
+block algebra with several hundred components) -- the cases of tests/_pca_update_cases.py, and the update /
+incremental doctests of the reference (raleigh/interfaces/pca.py:108-133) at their own size."""
+
+import numpy as np
+import pytest
+
+import _pca_update_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_update_with_tolerance(golden_dir):
+    cases.update_with_tolerance(golden_dir)
+
+
+def test_update_keeps_the_number_of_components(golden_dir):
+    cases.update_keeps_the_number_of_components(golden_dir)
+
+
+def test_incremental(golden_dir):
+    cases.incremental(golden_dir)
+
+
+def test_tall_batches():
+    cases.tall_batches()
+
+
+def test_refusals():
+    cases.refusals()
+
+
+def test_reference_doctests_incremental_and_update():
+    """generate(3000, 2000, 1000): pca(A, batch_size=1000, tol=0.05) -> 'max 2-norm 2e-02, Frobenius norm 4e-02';
+    pca(A[:2400], tol=0.05) then pca(A[2400:], have=...) -> '2e-02, 5e-02' for all rows (pca.py:108-133).
+    The Frobenius figure is what the tolerance controls: asserted no worse than the doctest's; the max-row
+    figure within the doctest's digit."""
+    from raleigh_amd.interfaces import pca, pca_error
+    from oracle.pca_data import generate
+    np.random.seed(1)
+    A, sigma, u, v = generate(3000, 2000, 1000, pca=True)
+    mean, trans, comps = pca(A, batch_size=1000, tol=0.05)
+    cases.check_shape_of_result(A, mean, trans, comps)
+    em, ef = pca_error(A, mean, trans, comps)
+    print('incremental: %d components, PCA error: max 2-norm %.0e, Frobenius norm %.0e' % (comps.shape[0], em, ef))
+    assert ef < 0.045 and em < 0.035
+    A0, A1 = A[:2400], A[2400:]
+    mean, trans, comps = pca(A0, tol=0.05)
+    em, ef = pca_error(A0, mean, trans, comps)
+    assert ef < 0.055 and em < 0.035
+    mean, trans, comps = pca(A1, have=(mean, trans, comps))
+    cases.check_shape_of_result(A, mean, trans, comps)
+    em, ef = pca_error(A, mean, trans, comps)
+    print('update: %d components, PCA error: max 2-norm %.0e, Frobenius norm %.0e' % (comps.shape[0], em, ef))
+    assert ef < 0.055 and em < 0.035
