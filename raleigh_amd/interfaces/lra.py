@@ -198,7 +198,7 @@ class LowerRankApproximation:
                         verb=verb, _mean=mean_v, _deflate=(right, C), _frob2=rest2)
         else:
             urank = max(1, rank * n1 // n)
-            urank = min(urank, max(1, min(n1, ncol) - k0))
+            urank = min(urank, max(1, min(n1, ncol - k0)))      # no more than the rank of E
             if verb > 0:
                 print('computing new %d components...' % urank)
             lra.compute(matrix, opt, rank=urank, svtol=svtol, shift=True, verb=verb, _mean=mean_v,

@@ -33,8 +33,8 @@ def test_refusals():
 def test_reference_doctests_incremental_and_update():
     """generate(3000, 2000, 1000): pca(A, batch_size=1000, tol=0.05) -> 'max 2-norm 2e-02, Frobenius norm 4e-02';
     pca(A[:2400], tol=0.05) then pca(A[2400:], have=...) -> '2e-02, 5e-02' for all rows (pca.py:108-133).
-    The Frobenius figure is what the tolerance controls: asserted no worse than the doctest's; the max-row
-    figure within the doctest's digit."""
+    The printed digits are asserted (the reference run in the build container gives 0.0223 / 0.0517 for the
+    update, this path on the CPU stand-in 0.0226 / 0.0514)."""
     from raleigh_amd.interfaces import pca, pca_error
     from oracle.pca_data import generate
     np.random.seed(1)
@@ -43,13 +43,13 @@ def test_reference_doctests_incremental_and_update():
     cases.check_shape_of_result(A, mean, trans, comps)
     em, ef = pca_error(A, mean, trans, comps)
     print('incremental: %d components, PCA error: max 2-norm %.0e, Frobenius norm %.0e' % (comps.shape[0], em, ef))
-    assert ef < 0.045 and em < 0.035
+    assert '%.0e' % ef == '4e-02' and '%.0e' % em == '2e-02'
     A0, A1 = A[:2400], A[2400:]
     mean, trans, comps = pca(A0, tol=0.05)
     em, ef = pca_error(A0, mean, trans, comps)
-    assert ef < 0.055 and em < 0.035
+    assert '%.0e' % ef == '5e-02' and '%.0e' % em == '2e-02'
     mean, trans, comps = pca(A1, have=(mean, trans, comps))
     cases.check_shape_of_result(A, mean, trans, comps)
     em, ef = pca_error(A, mean, trans, comps)
     print('update: %d components, PCA error: max 2-norm %.0e, Frobenius norm %.0e' % (comps.shape[0], em, ef))
-    assert ef < 0.055 and em < 0.035
+    assert '%.0e' % ef == '5e-02' and '%.0e' % em == '2e-02'

@@ -16,7 +16,7 @@ rng = np.random.default_rng(1)
 M, N, r = a.M, a.N, a.rank
 U, _ = np.linalg.qr(rng.standard_normal((M, r)).astype(np.float32))
 V, _ = np.linalg.qr(rng.standard_normal((N, r)).astype(np.float32))
-s = np.sort(rng.random(r).astype(np.float32))[::-1] ** 2 + 1e-3
+s = np.sort(rng.random(min(M, N)).astype(np.float32)) ** (-0.75); s = (s / s[0])[:r]     # as tools/pca_bench.py
 A = np.ascontiguousarray((U * s) @ V.T + 0.1, dtype=np.float32)
 pca(A[:2000], npc=10)       # warm the library up
 
