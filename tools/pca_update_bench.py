@@ -6,18 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument('--M', type=int, default=12000)
 ap.add_argument('--N', type=int, default=4000)
-ap.add_argument('--rank', type=int, default=400)
+ap.add_argument('--rank', type=int, default=2000)
 ap.add_argument('--batch', type=int, default=4000)
 ap.add_argument('--tol', type=float, default=0.05)
 a = ap.parse_args()
 from raleigh_amd.interfaces import pca, pca_error
 from raleigh_amd import _lib
-rng = np.random.default_rng(1)
+from oracle.pca_data import generate          # the reference's test-data generator (examples/pca/generate_matrix.py), restated
+np.random.seed(1)
 M, N, r = a.M, a.N, a.rank
-U, _ = np.linalg.qr(rng.standard_normal((M, r)).astype(np.float32))
-V, _ = np.linalg.qr(rng.standard_normal((N, r)).astype(np.float32))
-s = np.sort(rng.random(min(M, N)).astype(np.float32)) ** (-0.75); s = (s / s[0])[:r]     # as tools/pca_bench.py
-A = np.ascontiguousarray((U * s) @ V.T + 0.1, dtype=np.float32)
+A, sigma, u, v = generate(M, N, r, pca=True)
 pca(A[:2000], npc=10)       # warm the library up
 
 
