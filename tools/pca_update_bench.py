@@ -34,3 +34,9 @@ timed('incremental, batch %d' % a.batch, lambda: pca(A, batch_size=a.batch, tol=
 cut = M - a.batch
 m0 = pca(np.ascontiguousarray(A[:cut]), tol=a.tol)
 timed('update with last %d rows' % a.batch, lambda: pca(np.ascontiguousarray(A[cut:]), have=m0))
+if os.environ.get('PCA_UPDATE_PROFILE'):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    pca(np.ascontiguousarray(A[cut:]), have=m0)
+    _lib.synchronize()
+    pr.disable(); pstats.Stats(pr).sort_stats('tottime').print_stats(25)
