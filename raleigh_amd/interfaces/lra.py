@@ -145,7 +145,7 @@ class LowerRankApproximation:
         n = n0 + n1
         shift = self.__mean_v is not None
 
-        left, right = _orthogonal_times_orthonormal(left, right)
+        left, right = _orthogonal_times_orthonormal(left, right, diagonal=False)
         sigma0 = math.sqrt(float(numpy.abs(left.dots(left))[0])) if left.nvec() > 0 else 0.0
 
         row_norms2 = numpy.abs(matrix.dots())
@@ -289,7 +289,7 @@ class LowerRankApproximation:
         return self.__right_v
 
 
-def _orthogonal_times_orthonormal(left, right):
+def _orthogonal_times_orthonormal(left, right, diagonal=True):
     """Rewrites the product sum_i left_i right_i (left_i: vectors of the row dimension, right_i: of the
     column dimension) with orthonormal `right` and mutually orthogonal `left` in descending order of norm;
     returns the new pair.  (The job of lra.py:213-227, 311-326 and `_lra_ortho`, done with two Gram
@@ -297,7 +297,9 @@ def _orthogonal_times_orthonormal(left, right):
 
     H = R R^H = U M U^H:  R = (U M^1/2) Q with orthonormal Q = M^-1/2 U^H R;  L R = (L U M^1/2) Q; then
     (L U M^1/2)^H (L U M^1/2) = W D W^H gives L' = L U M^1/2 W, R' = W^H Q.  Directions of `right` with
-    no weight (M below rounding) carry nothing and are dropped."""
+    no weight (M below rounding) carry nothing and are dropped.  diagonal=False: only orthonormal `right`
+    is asked for (what update() needs of the pair it starts from; the reference skips that step
+    altogether unless told otherwise, lra.py:213)."""
     k = right.nvec()
     if k < 1:
         return left, right
@@ -311,12 +313,21 @@ def _orthogonal_times_orthonormal(left, right):
     # the k x k eigenproblems are the cost of an update once k reaches the thousands (0.7 s each at k = 1400
     # on the host, against 0.05 s of dense products): none for a pair that already has the form asked for,
     # one when `right` is orthonormal to rounding, as the stacked rows of update() are by construction
-    if numpy.abs(H - numpy.eye(k)).max() <= small:
+    E = H - numpy.eye(k)
+    dev = numpy.abs(E).max()
+    if not diagonal and dev <= math.sqrt(numpy.finfo(dtype).eps):
+        return left, right          # orthonormal enough to project with; the product is what matters
+    if dev <= small:
         d = numpy.real(numpy.diag(G))
         if numpy.abs(G - numpy.diag(d)).max() <= small * d.max() and numpy.all(numpy.diff(d) <= small * d.max()):
             return left, right
         B = numpy.eye(k, dtype=wide)
         Bi = B
+    elif dev <= math.sqrt(numpy.finfo(dtype).eps):
+        # R = H^1/2 Q with H^(+-1/2) from the series in E = H - I (|E|^3 is below rounding here)
+        E2 = E @ E
+        B = numpy.eye(k) + E / 2 - E2 / 8
+        Bi = numpy.conj(numpy.eye(k) - E / 2 + 3 * E2 / 8)
     else:
         mu, U = sla.eigh(H, driver='evd')
         keep = mu > numpy.finfo(dtype).eps * k * max(mu[-1], 0.0)
