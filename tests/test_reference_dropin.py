@@ -102,3 +102,28 @@ def test_complex_hermitian_with_reference_solver(ref_solver):
     assert status == 0
     exact = np.linalg.eigvalsh(H)
     assert np.allclose(np.sort(solver.eigenvalues), exact[-3:], rtol=1e-9)
+
+
+def test_reference_lower_rank_approximation_compute_and_update(ref_solver):
+    """The UNMODIFIED reference LowerRankApproximation (raleigh/interfaces/lra.py:79-379: compute, then update with
+    new rows) on this repository's AMatrix / Vectors: everything that path asks of the backend -- as_vectors() as a
+    view the update overwrites, append along both axes, svd, orthogonalize, new_vectors(ndarray), data()."""
+    rs, fake = ref_solver
+    from raleigh.interfaces.lra import LowerRankApproximation as RefLRA
+    from raleigh_amd.algebra.dense_matrix import AMatrix
+    from raleigh_amd.interfaces import pca_error
+    from oracle.pca_data import generate
+    np.random.seed(1)
+    A, sigma, u, v = generate(600, 400, 200, pca=True)
+    A0, A1 = A[:480], A[480:]
+    lra = RefLRA()
+    lra.compute(AMatrix(A0), opt=rs.Options(), tol=0.05, shift=True)
+    em, ef = pca_error(A0, lra.mean(), lra.left(), lra.right())
+    assert ef <= 0.05
+    lra.update(AMatrix(A1, copy_data=True), opt=rs.Options(), tol=0.05)
+    L, R = lra.left(), lra.right()
+    assert L.shape[0] == 600 and R.shape[1] == 400 and L.shape[1] == R.shape[0]
+    assert np.allclose(lra.mean(), A.mean(axis=0, keepdims=True), atol=1e-6)
+    assert np.abs(R @ R.T - np.eye(R.shape[0])).max() < 2e-4
+    em, ef = pca_error(A, lra.mean(), L, R)
+    assert ef <= 0.05
