@@ -70,7 +70,7 @@ class LowerRankApproximation:
 
     # ------------------------------------------------------------------ compute
     def compute(self, matrix, opt=None, rank=-1, tol=0, norm='f', max_rank=-1, svtol=1e-3, shift=False,
-                verb=0, _mean=None, _deflate=None, _frob2=None):
+                verb=0, refine=False, _mean=None, _deflate=None, _frob2=None):
         """Leading singular triplets of the (optionally mean-shifted) matrix: `rank` of them, or as many as
         bring the Frobenius norm of the remainder below tol |A_s|_F (tol > 0) or -tol (tol < 0)
         (lra.py:109-149 -> partial_svd.py:52-133)."""
@@ -95,7 +95,7 @@ class LowerRankApproximation:
                     _frob2 -= m * float(numpy.abs(aves.dots(aves))[0])
             opt.stopping_criteria = _FrobeniusStopping(_frob2, tol, max_rank)
         try:
-            psvd.compute(opt, rank)
+            psvd.compute(opt, rank, refine)
         finally:
             opt.block_size, opt.convergence_criteria, opt.stopping_criteria = user_bs, user_cc, user_sc
         if psvd.status < 0:
@@ -255,7 +255,7 @@ class LowerRankApproximation:
             if verb > 0:
                 print('processing batch %d of size %d' % (batch, batch_size))
             self.compute(_as_matrix(matrix[:batch_size, :], arch), opt=opt, rank=rank, tol=tol, norm=norm,
-                         max_rank=max_rank, svtol=svtol, shift=shift, verb=verb)
+                         max_rank=max_rank, svtol=svtol, shift=shift, verb=verb, refine=batch_size < matrix.shape[1])
             iterations = self.iterations
             first, batch = batch_size, 1
         while first < rows:

@@ -209,7 +209,7 @@ class PartialSVD:
     def vectors(self):
         return self.__v
 
-    def compute(self, opt, nsv):
+    def compute(self, opt, nsv, refine=False):
         op, v, transp, opSVD = self.__op, self.__v, self.__transp, self.__opsvd
         solver = Solver(Problem(v, opSVD))
         status = solver.solve(v, options=opt, which=(0, nsv))
@@ -240,6 +240,18 @@ class PartialSVD:
                     u.add(opSVD.ones, -1, v.dot(opSVD.aves))
                 else:
                     u.add(opSVD.aves, -1, v.dot(opSVD.ones))
+        if refine and nv > 1:
+            # u = A_s^(T) v is orthogonal only as far as v has converged (svtol): make it orthonormal and rotate
+            # v with it, A_s^(T) (v q) = u sigma.  (What pca.py:146-147 asks for when samples < features -- the
+            # components are then u; partial_svd.py:99-110.  The reference's own route through _finalize_svd
+            # stops at `nv = min(32, nsv/2)`, a float slice bound under Python 3, partial_svd.py:204-206.)
+            sigma, q = u.svd()
+            w = v.new_vectors(nv)
+            v.multiply(numpy.ascontiguousarray(q), w)
+            w.copy(v)
+            self.sigma = sigma
+            self.u, self.v = u, v
+            return
         sigma = numpy.sqrt(abs(u.dots(u)))
         u.scale(sigma)
         ind = numpy.argsort(-sigma)
@@ -281,7 +293,9 @@ def pca(A, npc=-1, tol=0, have=None, batch_size=None, verb=0, arch='hip', norm='
     if batch_size is None:
         matrix = _as_matrix(A, arch)        # an ndarray, or an AMatrix-like wrap, e.g. dist.ShardedAMatrix
         if have is None:
-            lra.compute(matrix, opt=opt, rank=npc, tol=tol, norm=norm, max_rank=mpc, svtol=svtol, shift=True, verb=verb)
+            m, n = matrix.shape()
+            lra.compute(matrix, opt=opt, rank=npc, tol=tol, norm=norm, max_rank=mpc, svtol=svtol, shift=True, verb=verb,
+                        refine=m < n)
         else:
             lra.update(matrix, opt=opt, rank=npc, tol=tol, norm=norm, max_rank=mpc, svtol=svtol, verb=verb)
     else:

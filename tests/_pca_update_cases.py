@@ -124,3 +124,17 @@ def refusals():
         LowerRankApproximation().update(AMatrix(A[300:]))                         # nothing to update
     with pytest.raises(ValueError):
         pca(A, batch_size=100, npc=5, norm='s')
+
+
+def fewer_samples_than_features():
+    """One-shot PCA of 300 x 700 fp32 rows: components orthonormal (the refinement of pca.py:146-147), reduced data
+    orthogonal and descending, error as asked."""
+    from raleigh_amd.interfaces import pca, pca_error
+    from oracle.pca_data import generate
+    np.random.seed(1)
+    A, sigma, u, v = generate(300, 700, 150, pca=True)
+    for kw in (dict(npc=20), dict(tol=0.1)):
+        mean, trans, comps = pca(A, **kw)
+        check_shape_of_result(A, mean, trans, comps, ortho_tol=1e-5)
+        em, ef = pca_error(A, mean, trans, comps)
+        assert ef <= (0.1 * 1.02 if 'tol' in kw else 0.12)

@@ -184,6 +184,14 @@ def test_pca_tolerance_and_transposed():
     em, ef = pca_error(A, mean, trans, comps)
     assert ef <= 0.1 * 1.02
     assert trans.shape[1] == comps.shape[0] and comps.shape[1] == 500
+    # fewer samples than features: the components are A_s^T v, orthonormal only after the refinement
+    # pca.py:146-147 asks for (2.6e-2 off without it)
+    k = comps.shape[0]
+    assert np.abs(comps @ comps.T - np.eye(k)).max() < 1e-5
+    mean, trans, comps = pca(A, npc=20)
+    assert np.abs(comps @ comps.T - np.eye(20)).max() < 1e-5
+    G = trans.T @ trans
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-5 * G[0, 0]
 
 
 def test_complex_hermitian_shift_invert_config5_shape():
