@@ -47,7 +47,7 @@ def test_reference_doctests_incremental_and_update():
     cases.check_shape_of_result(A, mean, trans, comps)
     em, ef = pca_error(A, mean, trans, comps)
     print('incremental: %d components, PCA error: max 2-norm %.0e, Frobenius norm %.0e' % (comps.shape[0], em, ef))
-    assert '%.0e' % ef == '4e-02' and '%.0e' % em == '2e-02'
+    assert ef <= 0.05 and '%.0e' % em == '2e-02'      # (0.044-0.046 from run to run: '4e-02' or '5e-02')
     A0, A1 = A[:2400], A[2400:]
     mean, trans, comps = pca(A0, tol=0.05)
     em, ef = pca_error(A0, mean, trans, comps)
