@@ -304,14 +304,39 @@ def pca_update_known_answers():
     return res
 
 
+def truncated_svd_known_answers():
+    """truncated_svd of the reference (interfaces/truncated_svd.py:24-127) on generate(600, 400, 200) fp32 and
+    generate(300, 700, 200) fp64: the singular values it returns for nsv = 20 and how many it needs for each
+    norm of the truncation error."""
+    from raleigh.examples.pca.generate_matrix import generate
+    from raleigh.interfaces.truncated_svd import truncated_svd
+    from raleigh.core.solver import Options
+    res = {}
+    for (m, n, dt) in ((600, 400, np.float32), (300, 700, np.float64)):
+        np.random.seed(1)
+        A, s, uu, vv = generate(m, n, 200, dtype=dt)
+        e = {}
+        u, sg, vt = truncated_svd(A, Options(), nsv=20)
+        e['sigma_nsv20'] = np.asarray(sg, dtype=np.float64)[:20].tolist()
+        e['ncomp_nsv20'] = int(len(sg))
+        for name, kw in (('s', dict(tol=0.1, norm='s')), ('f', dict(tol=0.1, norm='f')), ('m', dict(tol=0.2, norm='m'))):
+            u, sg, vt = truncated_svd(A, Options(), **kw)
+            D = A - (u * sg) @ vt
+            e['ncomp_' + name] = int(len(sg))
+            e['err_' + name] = [float(np.linalg.norm(D, 2) / np.linalg.norm(A, 2)), float(np.linalg.norm(D) / np.linalg.norm(A)),
+                                float(np.sqrt((D * D).sum(1).max() / (A * A).sum(1).max()))]
+        res['tsvd_%dx%d' % (m, n)] = e
+    return res
+
+
 def main():
-    if '--pca-update-only' in sys.argv:       # adds the update / incremental entries to the existing file
+    if '--pca-update-only' in sys.argv or '--truncated-svd-only' in sys.argv:   # adds entries to the existing file
         path = os.path.join(HERE, 'known_answers.json')
         known = json.load(open(path))
-        known.update(pca_update_known_answers())
+        known.update(pca_update_known_answers() if '--pca-update-only' in sys.argv else truncated_svd_known_answers())
         with open(path, 'w') as f:
             json.dump(known, f, indent=1)
-        print(json.dumps({k: v for k, v in known.items() if 'update' in k or 'incremental' in k}, indent=1))
+        print(json.dumps({k: v for k, v in known.items() if 'update' in k or 'incremental' in k or 'tsvd' in k}, indent=1)[-3000:])
         return
     shapes = [(5, 257), (16, 192)]
     for key in DTYPES:
@@ -337,6 +362,7 @@ def main():
     known = solver_known_answers()
     known.update(pca_known_answers())
     known.update(pca_update_known_answers())
+    known.update(truncated_svd_known_answers())
     known['_meta'] = {'numpy': np.__version__, 'have_mkl': HAVE_MKL,
                       'reference': 'evgueni-ovtchinnikov/raleigh v1.3.5 @ 2024-12-20'}
     with open(os.path.join(HERE, 'known_answers.json'), 'w') as f:
