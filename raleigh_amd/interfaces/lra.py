@@ -74,8 +74,10 @@ class LowerRankApproximation:
         """Leading singular triplets of the (optionally mean-shifted) matrix: `rank` of them, or as many as
         bring the Frobenius norm of the remainder below tol |A_s|_F (tol > 0) or -tol (tol < 0)
         (lra.py:109-149 -> partial_svd.py:52-133)."""
-        if norm != 'f':
-            raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
+        if norm not in ('f', 's', 'm'):
+            raise ValueError('norm %s is not supported' % repr(norm))
+        if norm != 'f' and _deflate is not None:
+            raise ValueError("only the Frobenius norm ('f') is available for an update")
         if opt is None:
             opt = Options()
         m, n = matrix.shape()
@@ -88,12 +90,16 @@ class LowerRankApproximation:
         if user_sc is None and rank < 0:
             if tol == 0:
                 raise ValueError('either the rank or tol must be given (interactive stopping is not available)')
-            if _frob2 is None:
+            if _frob2 is None and norm == 'f':
                 _frob2 = matrix.frobenius2()
                 if shift:       # |A_s|_F^2 = sum_i |a_i|^2 - m |mean|^2
                     aves = psvd.op_svd().aves
                     _frob2 -= m * float(numpy.abs(aves.dots(aves))[0])
-            opt.stopping_criteria = _FrobeniusStopping(_frob2, tol, max_rank)
+            if norm == 'f':
+                opt.stopping_criteria = _FrobeniusStopping(_frob2, tol, max_rank)
+            else:       # 's': sigma_k against sigma_0, 'm': the largest row of the remainder (truncated_svd.py:206-283)
+                from .truncated_svd import _TruncationStopping
+                opt.stopping_criteria = _TruncationStopping(matrix, psvd, tol, norm, max_rank, verb, shift=shift)
         try:
             psvd.compute(opt, rank, refine)
         finally:

@@ -9,8 +9,8 @@ Vectors / Matrix: the hot loop is the pair of dense products of ``_OperatorSVD.a
 Supported: a fixed number of components (``npc``) and the Frobenius-norm tolerance
 (``tol`` with ``norm='f'``), with the mean shift; samples >= features or the transposed
 case; the update of an existing approximation with new samples (``have``) and incremental
-PCA (``batch_size``), see lra.py.  Out of scope: interactive stopping, the
-'s' and 'm' norms.
+PCA (``batch_size``), see lra.py (Frobenius norm only); the 's' and 'm' norms for the one-shot
+case.  Out of scope: interactive stopping.
 """
 
 import math
@@ -278,15 +278,18 @@ def pca(A, npc=-1, tol=0, have=None, batch_size=None, verb=0, arch='hip', norm='
     order of norm (raleigh/interfaces/pca.py:16-164).
 
     npc : number of components, or negative to use `tol`;
-    tol : with npc < 0, stop when ||A_s - L R||_F <= tol ||A_s||_F (tol > 0) or <= -tol;
+    tol : with npc < 0, stop when the norm of A_s - L R is at most tol times that of A_s (tol > 0) or -tol;
+    norm : 'f' Frobenius, 's' largest singular value, 'm' largest row norm;
     have : (mean0, trans0, comps0) of data A0 seen earlier -- the result then describes
         numpy.concatenate((A0, A)); with neither npc nor tol, as many components as comps0 has;
     batch_size : incremental PCA, `batch_size` rows of A in HBM at a time;
     mpc : cap on the number of components when tol is used;
     svtol : singular value tolerance relative to the largest one.'''
     from .lra import LowerRankApproximation, _as_matrix
-    if norm != 'f':
-        raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
+    if norm not in ('f', 's', 'm'):
+        raise ValueError('norm %s is not supported' % repr(norm))
+    if norm != 'f' and (have is not None or batch_size is not None):
+        raise ValueError("only the Frobenius norm ('f') is available for an update / incremental PCA")
     if opt is None:
         opt = Options()
     lra = LowerRankApproximation(have)

@@ -33,16 +33,37 @@ class _VectorErrorCriteria:
 
 
 class _RowErrors:
-    """Norms of the rows of A - U S V^H as singular triplets arrive: |row_i|^2 minus the squares of the
-    row's coefficients (A v_j)_i (truncated_svd.py:130-203), accumulated on the device side by
-    `dots(transp=True)`."""
+    """Norms of the rows of A_ - U S V^H as singular triplets arrive (A_ = A, or A - e a with the mean shift):
+    |row_i|^2 minus the squares of the row's coefficients (A_ v_j)_i (truncated_svd.py:130-203), accumulated
+    on the device side by `dots(transp=True)`."""
 
-    def __init__(self, matrix, psvd):
+    def __init__(self, matrix, psvd, shift=False):
         self.op = matrix.as_operator()
         self.m, self.n = matrix.shape()
+        self.shifted = psvd.op_svd() if shift else None
         self.err2 = numpy.abs(matrix.dots()).astype(numpy.float64)
+        if shift:               # |a_i - a|^2 = |a_i|^2 - 2 Re(a_i . conj(a)) + |a|^2
+            if not hasattr(self.op, 'apply_r1'):
+                raise ValueError("norm 'm' with the mean shift needs a Matrix with apply_r1")
+            aves = self.shifted.aves
+            b = self.op.new_vectors(self.m, 1)
+            self.op.apply(self.shifted.aves_c, b)
+            s = float(numpy.abs(aves.dots(aves))[0])
+            self.err2 = numpy.maximum(self.err2 - 2 * numpy.real(b.data()[0]).astype(numpy.float64) + s, 0.0)
         self.initial = math.sqrt(float(numpy.amax(self.err2))) if self.m else 0.0
         self.ncon = 0
+
+    def _forward(self, x, y):
+        if self.shifted is not None:
+            self.shifted.forward(x, y)
+        else:
+            self.op.apply(x, y)
+
+    def _backward(self, x, z):
+        if self.shifted is not None:
+            self.shifted.backward(x, z)
+        else:
+            self.op.apply(x, z, transp=True)
 
     def update(self, x):
         ncon = x.nvec()
@@ -51,15 +72,15 @@ class _RowErrors:
             return
         sel = x.selected()
         x.select(new, sel[0] + self.ncon)
-        if self.m < self.n:         # x: left vectors; (A A^H x_j)_i conj(x_j)_i = sigma_j^2 |u_ij|^2
+        if self.m < self.n:         # x: left vectors; (A_ A_^H x_j)_i conj(x_j)_i = sigma_j^2 |u_ij|^2
             z = self.op.new_vectors(self.n, new)
-            self.op.apply(x, z, transp=True)
+            self._backward(x, z)
             y = self.op.new_vectors(self.m, new)
-            self.op.apply(z, y)
+            self._forward(z, y)
             q = numpy.real(x.dots(y, transp=True))
-        else:                       # x: right vectors; |(A v_j)_i|^2
+        else:                       # x: right vectors; |(A_ v_j)_i|^2
             y = self.op.new_vectors(self.m, new)
-            self.op.apply(x, y)
+            self._forward(x, y)
             q = numpy.real(y.dots(y, transp=True))
         x.select(sel[1], sel[0])
         self.err2 = numpy.maximum(self.err2 - numpy.maximum(q, 0.0), 0.0)
@@ -72,17 +93,17 @@ class _RowErrors:
 class _TruncationStopping:
     """The three norms of truncated_svd.py:206-283 without the interactive branch."""
 
-    def __init__(self, matrix, psvd, tol, norm, max_nsv, verb):
+    def __init__(self, matrix, psvd, tol, norm, max_nsv, verb, shift=False, frob2=None):
         self.tol, self.norm, self.max_nsv, self.verb = tol, norm, max_nsv, verb
         self.ncon = 0
         self.sigma0 = None
         self.f2 = self.frob = None
         self.rows = None
         if norm == 'f':
-            self.f2 = matrix.frobenius2()
+            self.f2 = matrix.frobenius2() if frob2 is None else frob2
             self.frob = math.sqrt(self.f2)
         elif norm == 'm':
-            self.rows = _RowErrors(matrix, psvd)
+            self.rows = _RowErrors(matrix, psvd, shift)
 
     def satisfied(self, solver):
         if solver.rcon <= self.ncon:

@@ -138,3 +138,23 @@ def fewer_samples_than_features():
         check_shape_of_result(A, mean, trans, comps, ortho_tol=1e-5)
         em, ef = pca_error(A, mean, trans, comps)
         assert ef <= (0.1 * 1.02 if 'tol' in kw else 0.12)
+
+
+def other_norms():
+    """One-shot PCA stopped by the largest row norm ('m') or the largest singular value ('s') of the remainder
+    (lra.py:109-149 -> truncated_svd.py:206-283 with the mean shift), both shapes of data."""
+    from raleigh_amd.interfaces import pca
+    from oracle.pca_data import generate
+    for (m, n) in ((600, 400), (300, 700)):
+        np.random.seed(1)
+        A, sigma, u, v = generate(m, n, 150, pca=True)
+        As = A - A.mean(axis=0)
+        smax = np.linalg.norm(As.astype(np.float64), 2)
+        rows = lambda D: np.sqrt((D * D).sum(1).max())
+        mean, trans, comps = pca(A, tol=0.05, norm='m')
+        assert rows(trans @ comps - As) <= 0.05 * rows(As) * 1.01
+        k_m = comps.shape[0]
+        mean, trans, comps = pca(A, tol=0.05, norm='s')
+        assert np.linalg.norm((trans @ comps - As).astype(np.float64), 2) <= 0.05 * smax * 1.01
+        mean, trans, comps = pca(A, tol=0.001, norm='m', mpc=10)
+        assert comps.shape[0] == 10 and k_m > 10
