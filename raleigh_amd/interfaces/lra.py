@@ -150,12 +150,13 @@ class LowerRankApproximation:
         n0 = left.dimension()
         n = n0 + n1
         shift = self.__mean_v is not None
+        if not shift:
+            raise ValueError('update without the mean shift is not available')
 
         left, right = _orthogonal_times_orthonormal(left, right, diagonal=False)
         sigma0 = math.sqrt(float(numpy.abs(left.dots(left))[0])) if left.nvec() > 0 else 0.0
 
-        row_norms2 = numpy.abs(matrix.dots())
-        frob2 = float(numpy.sum(row_norms2))
+        frob2 = matrix.frobenius2()
         mean_v = None
         if shift:
             # a1 = A1^T e1 / n1 ;  a = (n0 a0 + n1 a1) / n ;  d = a0 - a
@@ -186,16 +187,10 @@ class LowerRankApproximation:
 
         # C = A1_s R0^H: what the components in hand describe of the new rows (R0 real: no conjugation)
         lra = LowerRankApproximation()
-        probe = PartialSVD(matrix, shift=shift, mean=mean_v) if shift else None
         C = op.new_vectors(n1, k0)
-        if shift:
-            probe.op_svd().forward(right, C)
-        else:
-            op.apply(right, C)
+        PartialSVD(matrix, shift=True, mean=mean_v).op_svd().forward(right, C)
         rest2 = max(frob2 - float(numpy.sum(numpy.abs(C.dots(C)))), 0.0)     # |E|_F^2
 
-        if not shift:
-            raise ValueError('update without the mean shift is not available')
         if rest2 <= (numpy.finfo(dtype).eps * 16) ** 2 * frob2 or (rank < 0 and math.sqrt(rest2) <= tol * math.sqrt(frob2) / 4):
             pass        # the components in hand already describe the new rows: nothing to add
         elif rank < 0:
