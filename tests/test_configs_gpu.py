@@ -227,3 +227,74 @@ def test_config2_pca_20k_full_size():
     assert np.max(np.abs(sv - s[1:npc + 1])) < 1e-3 * s[1]
     assert np.max(np.abs(comps @ comps.T - np.eye(npc))) < 1e-3
     assert el < 5.0
+
+
+def test_config4_row_shard_pca_full_size():
+    """BASELINE config 4 is pca() of 500 000 x 40 000 fp32 rows over 8 GPUs: every GPU holds a 62 500 x 40 000
+    row shard (10 GB).  This is ONE such shard at full size on one GPU, built on the device from factors
+    (rows = (U s) V^T by rlh_dense_apply with 62 500 right-hand sides; U's first column constant, so the
+    mean-shifted shard is exactly sum_{k >= 1} s_k u_k v_k^T): the two dense products at that shape against
+    unit vectors (exact: every sum has one non-zero term) and against each other (<A x, y> = <x, A^T y>),
+    then 200 principal components against the generator's singular values."""
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    from raleigh_amd.algebra.dense_matrix import AMatrix
+    from raleigh_amd.interfaces import pca
+    from raleigh_amd import _lib
+    M, N, r, npc, m = 62500, 40000, 256, 200, 128
+    rng = np.random.default_rng(4)
+    U = rng.standard_normal((M, r)).astype(np.float32)
+    U[:, 0] = 1.0
+    V = rng.standard_normal((N, r)).astype(np.float32)
+    U, _ = np.linalg.qr(U)
+    V, _ = np.linalg.qr(V)
+    s = np.sort(rng.random(N).astype(np.float32)) ** (-0.75)
+    s = (s / s[0])[:r]
+    rows = Vectors(N, M, data_type=np.float32)                       # the shard: M vectors of dimension N
+    Matrix(np.ascontiguousarray(V)).apply(Vectors(np.ascontiguousarray(U * s)), rows)
+    A = AMatrix(rows)
+    op = A.as_operator()
+    assert op.shape() == (M, N)
+    # unit vectors: A^T e_i is row i, A e_j is column j -- to the last bit
+    pick_i = np.array([0, 1, 31249, 62499] + list(rng.integers(0, M, m - 4)))
+    E = np.zeros((m, M), dtype=np.float32)
+    E[np.arange(m), pick_i] = 1.0
+    w = Vectors(N, m, data_type=np.float32)
+    op.apply(Vectors(E), w, transp=True)
+    got = w.data()
+    for k in (0, 1, 2, 3, 77):
+        assert np.array_equal(got[k], rows.data(int(pick_i[k])))
+    pick_j = np.array([0, 39999] + list(rng.integers(0, N, m - 2)))
+    E = np.zeros((m, N), dtype=np.float32)
+    E[np.arange(m), pick_j] = 1.0
+    y = Vectors(M, m, data_type=np.float32)
+    op.apply(Vectors(E), y)
+    col = y.data()
+    for k in (0, 3, 77):
+        assert np.array_equal(col[:, int(pick_i[k])], got[k][pick_j])
+    # adjointness on random blocks, and the time of the pair
+    x = Vectors(N, m, data_type=np.float32)
+    x.fill_random()
+    z = Vectors(M, m, data_type=np.float32)
+    z.fill_random()
+    op.apply(x, y)
+    op.apply(z, w, transp=True)
+    lhs, rhs = z.dot(y), w.dot(x).T              # <A x_j, z_i> and <x_j, A^T z_i>
+    assert np.linalg.norm(lhs - rhs) <= 2e-4 * np.linalg.norm(lhs)
+    _lib.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        op.apply(x, y)
+        op.apply(y, w, transp=True)
+    _lib.synchronize()
+    pair = (time.time() - t0) / 3
+    print('config 4 shard 62500 x 40000 x %d: A x + A^T y in %.2f ms = %.1f TFLOP/s, %.2f TB/s of matrix reads'
+          % (m, pair * 1e3, 4.0 * M * N * m / pair / 1e12, 2.0 * M * N * 4 / pair / 1e12))
+    np.random.seed(1)
+    t0 = time.time()
+    mean, trans, comps = pca(A, npc=npc)
+    el = time.time() - t0
+    sv = np.linalg.norm(trans, axis=0)
+    print('config 4 shard: pca npc=%d in %.2f s, %d iterations' % (npc, el, pca.last['iterations']))
+    assert trans.shape == (M, npc) and comps.shape == (npc, N)
+    assert np.max(np.abs(sv - s[1:npc + 1])) < 1e-3 * s[1]
+    assert np.max(np.abs(comps @ comps.T - np.eye(npc))) < 1e-3
