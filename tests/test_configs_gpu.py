@@ -278,7 +278,7 @@ def test_config4_row_shard_pca_full_size():
     z.fill_random()
     op.apply(x, y)
     op.apply(z, w, transp=True)
-    lhs, rhs = z.dot(y), w.dot(x).T              # <A x_j, z_i> and <x_j, A^T z_i>
+    lhs, rhs = z.dot(y), w.dot(x)                # [i, j]: <z_j, A x_i> and <A^T z_j, x_i>
     assert np.linalg.norm(lhs - rhs) <= 2e-4 * np.linalg.norm(lhs)
     _lib.synchronize()
     t0 = time.time()
