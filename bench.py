@@ -389,6 +389,45 @@ def config_legs(L):
     out['config2'] = {'workload': 'pca of a dense 20000 x 20000 fp32 matrix, 200 components', 'seconds': round(el, 3),
                       'iterations': int(pca.last['iterations']), 'operator_seconds': round(float(pca.last['operator_time']), 3),
                       'max_sigma_error_over_sigma_max': float(np.max(np.abs(sv - s[1:npc + 1])) / s[1])}
+    del Am, mean, trans, comps
+    # ---- config 4: one GPU's row shard (62 500 of the 500 000 rows) at full size, built on the device from factors
+    from raleigh_amd.algebra.hip import Matrix
+    from raleigh_amd.algebra.dense_matrix import AMatrix
+    M, Nn, r, npc, m = 62500, 40000, 1280, 1000, 128
+    rng = np.random.default_rng(4)
+    U = rng.standard_normal((M, r)).astype(np.float32)
+    U[:, 0] = 1.0
+    V = rng.standard_normal((Nn, r)).astype(np.float32)
+    U, _ = np.linalg.qr(U)
+    V, _ = np.linalg.qr(V)
+    s = np.sort(rng.random(Nn).astype(np.float32)) ** (-0.75)
+    s = (s / s[0])[:r]
+    rows = Vectors(Nn, M, data_type=np.float32)
+    Matrix(np.ascontiguousarray(V)).apply(Vectors(np.ascontiguousarray(U * s)), rows)      # rows = (U s) V^T
+    del U, V
+    A4 = AMatrix(rows)
+    op4 = A4.as_operator()
+    x, w = Vectors(Nn, m, data_type=np.float32), Vectors(Nn, m, data_type=np.float32)
+    y = Vectors(M, m, data_type=np.float32)
+    x.fill_random()
+
+    def pair():
+        op4.apply(x, y)
+        op4.apply(y, w, transp=True)
+    t = timed_calls(L, pair, 5)
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    mean, trans, comps = pca(A4, npc=npc)
+    el = time.perf_counter() - t0
+    sv = np.linalg.norm(trans, axis=0)
+    out['config4_shard'] = {'workload': 'one of the 8 row shards of config 4 at full size: pca of 62500 x 40000 fp32 rows (10 GB, '
+                                        'built on the device), %d components' % npc,
+                            'dense_pair_ms': round(t, 3), 'dense_pair_tflops': round(4.0 * M * Nn * m / t / 1e9, 1),
+                            'dense_pair_frac_of_fp32_mfma_peak_157.3': round(4.0 * M * Nn * m / t / 1e9 / 157.3, 4),
+                            'matrix_read_gbs': round(2.0 * M * Nn * 4 / t / 1e6, 1),
+                            'seconds': round(el, 3), 'iterations': int(pca.last['iterations']),
+                            'operator_seconds': round(float(pca.last['operator_time']), 3),
+                            'max_sigma_error_over_sigma_max': float(np.max(np.abs(sv - s[1:npc + 1])) / s[1])}
     return out
 
 
