@@ -564,11 +564,13 @@ static int dense_impl(const DenseArgs &a) {
               (a.lda % 4 == 0) && (a.ldx % 4 == 0) && a.lda >= 4 && a.ldx >= 4 && a.nx > 0;
   }
   if constexpr (DT == RLH_S) {
-    // measured at 20000 x 20000 x 128: tiles with k contiguous 1.13 ms (first kernel) / 1.20 ms (second),
-    // column-major tiles 1.11 ms / 1.04 ms (RLH_DENSE_KERNEL=1|2 forces one: tunable)
+    // measured at 20000 x 20000 x 128, sustained: tiles with k contiguous 0.92 ms (first kernel) / 0.97 ms (second),
+    // column-major tiles 1.02 ms / 0.93 ms (RLH_DENSE_KERNEL=1|2 forces one: tunable)
     const int kern = env_int_d("RLH_DENSE_KERNEL", a.a_kcontig ? 1 : 2);
     if (mfma_ok && kern == 2) {
-      const int bk = env_int_d("RLH_DENSE_BK", 16);                  // tunable: 16 or 32
+      // tunable: 16 or 32.  Sustained rates (40 back-to-back calls, profiles/r02_gemm_shapes.txt): column-major
+      // tiles 110 TF with BK = 32 against 105 with 16 at 20000 x 20000 x 128 (119 against 114 at 40000^2)
+      const int bk = env_int_d("RLH_DENSE_BK", a.a_kcontig ? 16 : 32);
       if (a.m > 64) return bk == 32 ? launch_mfma2<128, 32>(a) : launch_mfma2<128, 16>(a);
       if (a.m > 32) return bk == 32 ? launch_mfma2<64, 32>(a) : launch_mfma2<64, 16>(a);
       return bk == 32 ? launch_mfma2<32, 32>(a) : launch_mfma2<32, 16>(a);
