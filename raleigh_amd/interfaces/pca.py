@@ -102,7 +102,7 @@ class _OperatorSVD:
         from ..algebra.hip.matrix import coefficients_into
         c1 = self._coefficients(z.nvec(), 1)
         coefficients_into(c1, z, self.ones)                               # s = e^T z
-        self.op.apply_r1(z, y, True, self.aves, c1)                       # y = A^T z - a s^T
+        self.op.apply_r1(z, y, True, self.aves_c, c1)                     # y = A^H z - conj(a) s^T
 
     def apply(self, x, y):
         m, n = self.op.shape()
@@ -120,7 +120,7 @@ class _OperatorSVD:
             c0, c1 = self._coefficients(k, 0), self._coefficients(k, 1)
             if self.transp:
                 coefficients_into(c0, x, self.ones)                       # s = e^T x
-                self.op.apply_r1(x, z, True, self.aves, c0)               # z = A^T x - a s^T
+                self.op.apply_r1(x, z, True, self.aves_c, c0)             # z = A^H x - conj(a) s^T
                 if self.deflate is not None:
                     _project_out(z, self.deflate[0])                      # z = (I - R^H R) z
                 coefficients_into(c1, z, self.aves_c)                     # t = a^T z
@@ -138,7 +138,7 @@ class _OperatorSVD:
                     _project_out(y, self.deflate[0])
         elif self.transp:
             self.op.apply(x, z, transp=True)
-            z.add(self.aves, -1.0, x.dot(self.ones))                      # - a (e^T x)
+            z.add(self.aves_c, -1.0, x.dot(self.ones))                    # - conj(a) (e^T x)
             self.op.apply(z, y)
             y.add(self.ones, -1.0, z.dot(self.aves_c))                    # - e (a^T z)
         else:
@@ -237,9 +237,9 @@ class PartialSVD:
             op.apply(v, u, transp)
             if self.__shift:            # u = A_s v (or A_s^T v)
                 if not transp:
-                    u.add(opSVD.ones, -1, v.dot(opSVD.aves))
+                    u.add(opSVD.ones, -1, v.dot(opSVD.aves_c))     # - e (a^T v)
                 else:
-                    u.add(opSVD.aves, -1, v.dot(opSVD.ones))
+                    u.add(opSVD.aves_c, -1, v.dot(opSVD.ones))     # - conj(a) (e^T v)
         if refine and nv > 1:
             # u = A_s^(T) v is orthogonal only as far as v has converged (svtol): make it orthonormal and rotate
             # v with it, A_s^(T) (v q) = u sigma.  (What pca.py:146-147 asks for when samples < features -- the
