@@ -108,10 +108,16 @@ struct Context {
   char *result_hd = nullptr;     // device-side address of result_h (zero-copy result delivery)
   size_t result_h_bytes = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  // raised by a kernel that gave up on a bounded spin (persistent triangular solve): mapped pinned word
+  unsigned *async_err_h = nullptr;
+  unsigned *async_err_d = nullptr;
 };
 
 Context &ctx();
 int require_ready();
+// non-zero (and the error text set) once a kernel has reported a failure it could not return: checked by every
+// call that synchronises with the stream and by the calls that launch such kernels
+int check_async_error();
 
 // Returns a pinned host slot and its device twin; the caller fills `*h`,
 // then calls ring_commit(slot, bytes) which enqueues the H2D copy.  After the

@@ -35,6 +35,15 @@ int require_ready() {
   return 0;
 }
 
+int check_async_error() {
+  Context &c = ctx();
+  if (c.async_err_h && *(volatile unsigned *)c.async_err_h != 0) {
+    set_error("a device kernel gave up waiting for a dependency (persistent triangular solve): its results are invalid");
+    return 1;
+  }
+  return 0;
+}
+
 int ring_acquire(size_t bytes, int *slot, void **h, void **d) {
   Context &c = ctx();
   RLH_REQUIRE(bytes <= kRingSlotBytes, "coefficient block of %zu bytes exceeds the %zu-byte staging slot",
@@ -93,7 +102,7 @@ int fetch_result(void *h_out, const void *d_src, size_t bytes) {
     RLH_HIP(hipMemcpyAsync(h_out, d_src, bytes, hipMemcpyDeviceToHost, c.stream));
     RLH_HIP(hipStreamSynchronize(c.stream));
   }
-  return 0;
+  return check_async_error();
 }
 
 }  // namespace rlh
@@ -138,6 +147,9 @@ int rlh_init(int device) {
   RLH_HIP(hipMalloc((void **)&c.work, kWorkspaceBytes));
   RLH_HIP(hipEventCreate(&c.t0));
   RLH_HIP(hipEventCreate(&c.t1));
+  RLH_HIP(hipHostMalloc((void **)&c.async_err_h, 64, hipHostMallocMapped));
+  *c.async_err_h = 0;
+  RLH_HIP(hipHostGetDevicePointer((void **)&c.async_err_d, c.async_err_h, 0));
   c.device = device;
   c.ready = true;
   if (int rc = ensure_result(1u << 20)) return rc;
@@ -156,6 +168,7 @@ int rlh_finalize(void) {
   (void)hipFree(c.work);
   if (c.result_d) (void)hipFree(c.result_d);
   if (c.result_h) (void)hipHostFree(c.result_h);
+  if (c.async_err_h) (void)hipHostFree(c.async_err_h);
   (void)hipStreamDestroy(c.own_stream);
   c = Context();
   return 0;
@@ -172,7 +185,7 @@ int rlh_set_stream(void *hip_stream) {
 int rlh_sync(void) {
   if (int rc = require_ready()) return rc;
   RLH_HIP(hipStreamSynchronize(ctx().stream));
-  return 0;
+  return check_async_error();
 }
 
 int rlh_mem_info(int64_t *free_bytes, int64_t *total_bytes) {

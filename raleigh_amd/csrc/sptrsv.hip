@@ -9,13 +9,9 @@
 //  * rlh_sptrsv_create turns a triangular CSR factor into a device operator: rows are grouped into
 //    dependency LEVELS (a row's level is one more than the largest level among the rows it
 //    references), the rows of a level are independent;
-//  * rlh_sptrsv_solve_chain applies a chain of such operators to a block of m vectors at once: the
-//    block is transposed into a row-major scratch [row][vector] (the m values of a row are then
-//    one contiguous run: a gather of a referenced row is one or two cache lines that are used in
-//    full), one small kernel per level -- LPR lanes per row, each lane owning a 16-byte piece of the
-//    row (a run of consecutive small levels shares ONE launch: a single 1024-thread workgroup walks
-//    them behind workgroup barriers) -- and transposed back.  The launches of one chain are captured
-//    into a hipGraph and replayed (the launch overhead, not the arithmetic, bounds it).
+//  * rlh_sptrsv_solve_chain applies a chain of such operators to a block of m vectors at once in ONE
+//    persistent launch: rows wait for the rows they read, not for their level (design notes at the
+//    device section below).  The reference applies 2 m sequential mkl_dcsrtrsv on the host.
 #include <math.h>
 
 #include <algorithm>
@@ -33,25 +29,35 @@ struct rlh_factors {
   std::vector<char> lval, uval;    // L strictly lower (unit diagonal implied), U upper incl. diagonal
 };
 
+namespace rlh { struct TrsvUnit; struct TrsvRow; }
+struct TrsvPlan {                  // units and far / near split of an operator for `pl` lanes across the pieces of a row
+  int pl = 0;
+  int64_t nunits = 0;
+  rlh::TrsvUnit *units = nullptr;  // device
+  rlh::TrsvRow *rows = nullptr;    // device, by position
+};
+
 struct rlh_sptrsv {
   int dtype;
   int64_t n, nnz;                  // nnz: stored off-diagonal entries
   int lower, unit;
-  // device arrays in LEVEL order: position p holds row lev_rows[p]; its off-diagonal entries are
-  // cols / vals [rowptr[p], rowptr[p + 1]) (column = ORIGINAL row number), its 1 / diagonal dinv[p]
-  int64_t *rowptr;                 // n + 1
+  // device arrays in LEVEL order: position p holds row lev_rows[p]; its off-diagonal entries are one
+  // contiguous run of cols / vals: x entries (column = ORIGINAL row number; sorted by the position of that row, so
+  // the oldest dependencies come first), then rhs entries (see sptrsv_build)
   int32_t *cols;
   void *vals;
-  void *dinv;                      // nullptr: unit diagonal
   int32_t *lev_rows;               // the rows ordered by level
-  std::vector<int64_t> lev_off;    // host: first position of every level in lev_rows, nlevels + 1
-  int64_t *lev_off_d;              // device copy (the chain kernel walks several levels per launch)
+  std::vector<int64_t> lev_off;    // host: first position of every level, nlevels + 1
+  std::vector<int64_t> rowptr_h;   // host: first entry of every position, n + 1
+  std::vector<int32_t> dep_pos_h;  // host: per x entry, the position of the row it reads (plans are built from it)
+  std::vector<int32_t> nx_h;       // host: x entries of every position (its rhs entries follow them)
+  int64_t entries, nblocks;        // stored entries after the block transform; diagonal blocks
+  TrsvPlan plan[2];
+  int plan_lru;
   int64_t device_bytes;
-  // scratch and captured launch sequence of the chain this operator heads
+  // scratch (control words + block images) of the chain this operator heads
   void *work;
   int64_t work_bytes;
-  hipGraphExec_t graph;
-  uint64_t graph_key;
 };
 
 namespace rlh {
@@ -150,326 +156,546 @@ static int ilut_factor(int64_t n, const int64_t *indptr, const int32_t *indices,
   return 0;
 }
 
-// ------------------------------------------------------------------ device kernels
-template <typename T, int EPL> struct alignas(16) Piece { T e[EPL]; };
+// ------------------------------------------------------------------ device side
+//
+// One PERSISTENT launch per chain.  The dependency levels are not kernel boundaries
+// any more: every row waits for exactly the rows it reads.
+//
+//  * Scratch.  The n x m block is cut into 16-byte pieces; the pieces of a row are dealt to at most 8
+//    GROUPS (ppt pieces per row and group) and every group owns its own image of the block,
+//    [slot][group][row][ppt] pieces: slot 0 the right-hand side, slot k + 1 the result of operator k.
+//    The columns of a block are independent right-hand sides, so the groups never exchange a byte.
+//  * Teams.  A group is solved by the workgroups of ONE XCD, whichever XCD claims it first (the
+//    hardware id is read with s_getreg, claims are agent-scope atomics, a late or missing XCD costs
+//    time, never correctness): the rows one workgroup finishes reach the others through that XCD's
+//    own L2 -- plain 16-byte stores, L1-bypassing (sc1) 16-byte loads -- without a fence and without
+//    a trip to the memory side of the fabric.
+//  * Hand-off.  The data is its own flag: the result slots are pre-filled with one particular NaN
+//    (every 32-bit word 0xFFFFDEAD), a consumer re-reads a piece until none of its 8-byte halves
+//    carries that pattern, a producer never stores it (a result that happens to be this NaN is
+//    rewritten as the canonical quiet NaN).  A piece is written once, by one lane, in one store.
+//  * Queue.  The rows are cut into UNITS of at most 256 (row, lane) tasks inside one level, listed
+//    in level order; workgroups take units from one counter per group.  A unit only ever waits for
+//    units taken earlier, which are held by resident workgroups: no placement or residency
+//    assumption, no grid barrier.
+//  * Throttle.  Polling every referenced piece from the moment a unit is taken would swamp the L2, so
+//    a unit records the last unit its FAR entries (dependencies at least kNearWindow units back) and
+//    its NEAR entries need, every unit raises a done word when its stores have left, and one lane
+//    sleeps on those two words -- first coarsely on a word 32 units earlier -- before the workgroup
+//    gathers.  The words are hints (a stale one costs polls, not correctness).
+//  * Every spin is bounded (wall clock, and an error word another workgroup may have raised): a
+//    protocol failure ends the launch with NaNs in the result and rlh_sync / the next call report it.
 
-// W[r][v] = B[perm ? perm[r] : r, v] (row-major scratch, leading dimension ldw, columns >= m zeroed)
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_transpose_in(const T *__restrict__ B, int64_t ldb, const int64_t *__restrict__ perm,
-                                                         T *__restrict__ W, int ldw, int64_t n, int m) {
-  constexpr int EPL = 16 / (int)sizeof(T);
-  const int ppr = ldw / EPL;                               // 16-byte pieces per row
-  const int64_t total = n * ppr;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
-    const int64_t r = t / ppr;
-    const int p = (int)(t - r * ppr);
-    const int64_t src = perm ? perm[r] : r;
-    Piece<T, EPL> out;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int v = p * EPL + e;
-      out.e[e] = v < m ? B[src + (int64_t)v * ldb] : zero_of(T{});
-    }
-    *reinterpret_cast<Piece<T, EPL> *>(W + r * ldw + p * EPL) = out;
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_transpose_out(const T *__restrict__ W, int ldw, const int64_t *__restrict__ perm,
-                                                          T *__restrict__ X, int64_t ldx, int64_t n, int m) {
-  constexpr int EPL = 16 / (int)sizeof(T);
-  const int ppr = ldw / EPL;
-  const int64_t total = n * ppr;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
-    const int64_t r = t / ppr;
-    const int p = (int)(t - r * ppr);
-    const int64_t dst = perm ? perm[r] : r;
-    const Piece<T, EPL> in = *reinterpret_cast<const Piece<T, EPL> *>(W + r * ldw + p * EPL);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int v = p * EPL + e;
-      if (v < m) X[dst + (int64_t)v * ldx] = in.e[e];
-    }
-  }
-}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float  neg_of(float a)  { return -a; }
 __device__ __forceinline__ double neg_of(double a) { return -a; }
 __device__ __forceinline__ c32 neg_of(c32 a) { return c32{-a.re, -a.im}; }
 __device__ __forceinline__ c64 neg_of(c64 a) { return c64{-a.re, -a.im}; }
+__device__ __forceinline__ float  one_of(float)  { return 1.f; }
+__device__ __forceinline__ double one_of(double) { return 1.0; }
+__device__ __forceinline__ c32 one_of(c32) { return c32{1.f, 0.f}; }
+__device__ __forceinline__ c64 one_of(c64) { return c64{1.0, 0.0}; }
+template <typename T> struct Halves64 { static constexpr bool value = false; };   // 8-byte real parts: the pattern sits in the high word
+template <> struct Halves64<double> { static constexpr bool value = true; };
+template <> struct Halves64<c64> { static constexpr bool value = true; };
 
-// Sum of the 16-byte pieces of the lanes that differ in the bits [lpr, lpr * sl) of the lane number
-// (the slices of one row).
-template <typename T, int EPL>
-__device__ __forceinline__ void reduce_slices(Piece<T, EPL> &acc, int lpr, int sl) {
-  constexpr int W = (int)(sizeof(T) * EPL / 4);
-  union U { Piece<T, EPL> p; int w[W]; };
-  for (int off = lpr; off < lpr * sl; off <<= 1) {
-    U a, b;
-    a.p = acc;
-#pragma unroll
-    for (int k = 0; k < W; ++k) b.w[k] = __shfl_xor(a.w[k], off);
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) acc.e[k] = add_of(acc.e[k], b.p.e[k]);
+
+constexpr unsigned kSentinel = 0xFFFFDEADu;     // as a float, and as the high word of a double: a NaN
+constexpr int kNearWindow = 12;                 // units: dependencies closer than this are gathered last
+constexpr int kCoarse = 32;                     // units between the coarse and the fine done word of a wait
+constexpr int kMaxXcd = 8;
+constexpr int kCtrlHead = 32;                   // words: [0] next group, [1] error, [2] census
+constexpr unsigned long long kSpinTicks = 400000000ull;      // 4 s of the 100 MHz wall clock
+
+struct alignas(16) TrsvUnit {
+  int32_t p0; uint16_t nr; uint8_t lg_lr, pad;
+  int32_t far_unit;             // the last unit a far entry reads (-1: none)
+  int32_t near_unit;            // the last unit any x entry reads (-1: none)
+  int32_t thr_unit;             // far entries read units <= thr_unit; the near ones are polled for once it is done (-1: at once)
+  int32_t pad2[3];
+};
+struct alignas(16) TrsvRow { int64_t e0; int32_t nfar; uint16_t nnear, nrhs; };   // x entries far | near, then rhs entries
+
+struct TrsvOp {
+  const TrsvUnit *units;
+  const TrsvRow *rows;
+  const int32_t *lev_rows, *cols;
+  const void *vals;
+  int32_t unit0, nunits;
+};
+
+struct TrsvArgs {
+  TrsvOp op[8];
+  int nops, total_units, ngroups, ppt, pl, done_stride, tune;
+  int64_t n8;
+  u32x4 *scratch;
+  unsigned *ctrl;
+  unsigned *err_host;                           // mapped host word (Context::async_err)
+  unsigned long long *trace;                    // diagnostics (RLH_SPTRSV_TRACE): 16 words per unit of group 0, or null
+};
+
+template <typename T> struct PieceOf {
+  static constexpr int EPL = 16 / (int)sizeof(T);
+  union U { u32x4 w; T e[EPL]; };
+};
+
+// a piece some lane has stored (true) or the pre-filled pattern (false); 8-byte halves are judged separately
+template <typename T> __device__ __forceinline__ bool piece_ready(u32x4 w) {
+  if constexpr (Halves64<T>::value) return w.y != kSentinel && w.w != kSentinel;              // double, complex double
+  else return w.x != kSentinel && w.y != kSentinel && w.z != kSentinel && w.w != kSentinel;   // float, complex float
+}
+template <typename T> __device__ __forceinline__ u32x4 piece_clean(u32x4 w) {
+  if constexpr (Halves64<T>::value) {
+    if (w.y == kSentinel) { w.x = 0u; w.y = 0x7FF80000u; }
+    if (w.w == kSentinel) { w.z = 0u; w.w = 0x7FF80000u; }
+  } else {
+    if (w.x == kSentinel) w.x = 0x7FC00000u;
+    if (w.y == kSentinel) w.y = 0x7FC00000u;
+    if (w.z == kSentinel) w.z = 0x7FC00000u;
+    if (w.w == kSentinel) w.w = 0x7FC00000u;
+  }
+  return w;
+}
+
+// L1-bypassing 16-byte loads (the asm carries its own wait: hipcc does not count an asm load)
+__device__ __forceinline__ u32x4 load_sc1(const u32x4 *p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void load4_sc1(const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, u32x4 &x0,
+                                          u32x4 &x1, u32x4 &x2, u32x4 &x3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\t"
+      "global_load_dwordx4 %1, %5, off sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+
+struct Watch {                                  // bounds every spin of one thread
+  unsigned *ctrl, *err_host;
+  unsigned long long t0;
+  unsigned spins;
+  bool dead;
+  __device__ __forceinline__ bool expired() {  // call once per failed poll
+    if (dead) return true;
+    if ((++spins & 255u) == 0) {
+      if (__hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+      else if ((unsigned long long)wall_clock64() - t0 > kSpinTicks) {
+        __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dead = true;
+      }
+    }
+    return dead;
+  }
+};
+
+__device__ __forceinline__ void wait_word(const unsigned *w, int sleep, Watch &watch) {
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    if (sleep > 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(1);
+    if (watch.expired()) break;
   }
 }
-
-// One row of one level: W[r][:] = (W[r][:] - sum_e vals[e] W[cols[e]][:]) * dinv[r].  The row is worked
-// on by LPR x sl lanes of one wave: lane `piece` of LPR owns a 16-byte piece of the row (more than one
-// when the block has more than 64 pieces per row), slice `slice` of sl takes every sl-th entry -- the
-// gathers of a row are dependent loads (column index, then the referenced row), so the entries of a
-// long row are spread over lanes instead of being walked by one -- and the slices are summed by
-// lane shuffles.
-template <typename T, int LPR>
-__device__ __forceinline__ void trsv_row(int64_t r, int64_t e0, int64_t e1, int64_t pos, int piece, int slice, int sl,
-                                         const int32_t *__restrict__ cols, const T *__restrict__ vals,
-                                         const T *__restrict__ dinv, T *W, int ldw, int ppr) {
-  constexpr int EPL = 16 / (int)sizeof(T);
-  using P = Piece<T, EPL>;
-  for (int p = piece; p - piece < ppr; p += LPR) {         // (one trip unless the block has more than 64 pieces per row)
-    const bool live = p < ppr;                             // (all lanes of the row stay in the shuffles)
-    const int pc = live ? p : ppr - 1;
-    T *wr = W + r * ldw + pc * EPL;
-    P acc;
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) acc.e[k] = zero_of(T{});
-    if (slice == 0) acc = *reinterpret_cast<const P *>(wr);
-    // (eight entries per trip instead of four -- one round of index loads and one of row gathers for the usual row --
-    // changed nothing: 45.06 vs 45.03 ms on the config-3 surrogate, whose 9 120 levels cost 4.9 us each as graph nodes
-    // whatever their kernels do)
-    for (int64_t e = e0 + slice; e < e1; e += 4 * (int64_t)sl) {
-      int32_t c[4];
-      T v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t ee = e + (int64_t)u * sl;
-        const int64_t ec = ee < e1 ? ee : e;               // surplus slots repeat this lane's entry with value 0
-        c[u] = cols[ec];
-        v[u] = ee < e1 ? neg_of(vals[ec]) : zero_of(T{});
-      }
-      P x[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const P *>(W + (int64_t)c[u] * ldw + pc * EPL);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) fma_acc(acc.e[k], v[u], x[u].e[k]);
-    }
-    if (sl > 1) reduce_slices<T, EPL>(acc, LPR, sl);
-    if (slice == 0 && live) {
-      if (dinv) {
-        const T d = dinv[pos];
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) acc.e[k] = mul_of(acc.e[k], d);
-      }
-      *reinterpret_cast<P *>(wr) = acc;
-    }
-  }
+// one lane: sleep until unit k of this group (a hint) is done -- coarsely on an earlier unit's word first
+__device__ __forceinline__ void wait_unit(const unsigned *done, int k, Watch &watch) {
+  if (k < 0) return;
+  if (k >= kCoarse) wait_word(done + (k - kCoarse), 32, watch);
+  wait_word(done + k, 1, watch);
 }
 
-// One large dependency level (positions [p0, p0 + nrows)): LPR x sl lanes per row over as many
-// workgroups as the level fills.
-template <typename T, int LPR>
-__global__ __launch_bounds__(256) void trsv_level_kernel(const int32_t *__restrict__ rows, int64_t p0, int nrows, int sl,
-                                                         const int64_t *__restrict__ rowptr, const int32_t *__restrict__ cols,
-                                                         const T *__restrict__ vals, const T *__restrict__ dinv,
-                                                         T *W, int ldw, int ppr) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int lpt = LPR * sl;                                // lanes per row (a power of two, at most 64)
-  const int64_t rloc = gid / lpt;
-  const int l = (int)(gid % lpt);
-  if (rloc >= nrows) return;                               // (whole groups of lpt lanes: a row's shuffles stay among its own lanes)
-  const int64_t pos = p0 + rloc;
-  trsv_row<T, LPR>(rows[pos], rowptr[pos], rowptr[pos + 1], pos, l % LPR, l / LPR, sl, cols, vals, dinv, W, ldw, ppr);
-}
-
-constexpr int kChainLevels = 8192;           // levels per launch of the chain kernel (their offsets sit in the LDS)
-
-// A run of SMALL consecutive levels [l0, l1) in ONE workgroup of 1024 threads: the levels follow each
-// other behind a workgroup barrier (the rows a level reads were written by waves of the same
-// workgroup: workgroup-scope release / acquire is what __syncthreads() provides), so a long chain of
-// tiny levels -- an FE matrix in a banded ordering has thousands of levels of a few dozen rows --
-// costs one launch instead of one launch per level.  The critical path of such a chain is the
-// dependent loads of one level after the other: the offsets of the levels are copied to the LDS up
-// front, and a thread's row descriptor for the NEXT level (row, entry range: independent of the
-// solution) is fetched while the current level is computed.
-template <typename T, int LPR>
-__global__ __launch_bounds__(1024) void trsv_chain_kernel(const int32_t *__restrict__ rows, const int64_t *__restrict__ lev_off,
-                                                          int l0, int l1, int sl, const int64_t *__restrict__ rowptr,
-                                                          const int32_t *__restrict__ cols, const T *__restrict__ vals,
-                                                          const T *__restrict__ dinv, T *W, int ldw, int ppr) {
-  constexpr int EPL = 16 / (int)sizeof(T);
-  using P = Piece<T, EPL>;
-  __shared__ int s_off[kChainLevels + 1];                  // first position of every level, relative to the run's first
-  __shared__ __attribute__((aligned(16))) P s_red[16 * LPR];   // per-wave partial sums of a row spread over several waves
-  const int tid = threadIdx.x;
-  const int lpt = LPR * sl;
-  const int64_t base = lev_off[l0];
-  for (int k = tid; k <= l1 - l0; k += 1024) s_off[k] = (int)(lev_off[l0 + k] - base);
-  __syncthreads();
-  // Lanes per row of a level: the operator's LPR x sl, doubled while all rows of the level still fit the
-  // workgroup -- the single rows at the end of a direct factor (dense separator blocks: thousands of entries,
-  // one row per level) are walked by all 1024 threads instead of 64 lanes.  Up to 64 lanes the slices of a row
-  // are summed by shuffles; beyond, every wave of the row leaves its partial in the LDS.
-  const bool can_widen = ppr <= LPR;                       // (one trip over the pieces)
-  auto lanes_of = [&](int k) -> int {
-    int wl = lpt;
-    if (can_widen && k < l1 - l0) {
-      const int nr = s_off[k + 1] - s_off[k];
-      while (wl * 2 * nr <= 1024) wl *= 2;
-    }
-    return wl;
-  };
-  struct Desc { int64_t pos, r, e0, e1; bool live; int wl; };
-  auto fetch = [&](int k) -> Desc {
-    Desc d;
-    d.wl = lanes_of(k);
-    const int my_row = tid / d.wl;
-    d.live = k < l1 - l0 && my_row < s_off[k + 1] - s_off[k];
-    d.pos = base + (d.live ? s_off[k] + my_row : 0);
-    d.r = rows[d.pos];
-    d.e0 = rowptr[d.pos];
-    d.e1 = rowptr[d.pos + 1];
-    return d;
-  };
-  Desc next = fetch(0);
-  for (int k = 0; k < l1 - l0; ++k) {
-    const Desc cur = next;
-    next = fetch(k + 1);                                   // in flight during this level
-    const int wl = cur.wl;                                 // (workgroup-uniform)
-    if (wl <= 64) {
-      const int my_l = tid % wl;
-      if (cur.live) trsv_row<T, LPR>(cur.r, cur.e0, cur.e1, cur.pos, my_l % LPR, my_l / LPR, wl / LPR, cols, vals, dinv, W, ldw, ppr);
-      const int64_t tasks = (int64_t)(s_off[k + 1] - s_off[k]) * wl;
-      for (int64_t t = tid + 1024; t < tasks; t += 1024) {   // levels of more than 1024 (row, lane) tasks
-        const int64_t pos = base + s_off[k] + t / wl;
-        const int l = (int)(t % wl);
-        trsv_row<T, LPR>(rows[pos], rowptr[pos], rowptr[pos + 1], pos, l % LPR, l / LPR, wl / LPR, cols, vals, dinv, W, ldw, ppr);
-      }
+// which group does XCD `xcc` solve in its round `round`?  The first of its workgroups to ask takes the next
+// unclaimed group for the XCD; -1: none left.
+__device__ __forceinline__ int claim_group(unsigned *ctrl, unsigned xcc, int round, int ngroups, Watch &watch) {
+  unsigned *slot = ctrl + kCtrlHead + xcc * (unsigned)(ngroups + 1) + (unsigned)round;
+  unsigned v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v == 0) {
+    unsigned expected = 0;
+    if (__hip_atomic_compare_exchange_strong(slot, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      v = __hip_atomic_fetch_add(ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2u;
+      __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      // a row over wl / 64 whole waves: slice = lane of the row / LPR takes every (wl / LPR)-th entry
-      const int l = tid % wl, piece = l % LPR, slice = l / LPR, nsl = wl / LPR;
-      const int pc = piece < ppr ? piece : ppr - 1;
-      P acc;
+      v = 1;
+    }
+  }
+  while (v == 1) {
+    __builtin_amdgcn_s_sleep(2);
+    if (watch.expired()) return -1;
+    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int g = (int)v - 2;
+  return g < ngroups ? g : -1;
+}
+
+template <typename T> struct Batch { int32_t c[4]; T v[4]; unsigned rhs; };
+
+// entries e, e + sl, e + 2 sl, e + 3 sl of a row (those beyond `end` repeat the first with value 0); bit u of `rhs`:
+// entry u lies at or beyond end_x, i.e. it reads the right-hand side image, not the result image
+template <typename T>
+__device__ __forceinline__ Batch<T> load_batch(const int32_t *__restrict__ cols, const T *__restrict__ vals, int64_t e, int64_t end, int sl,
+                                               int64_t end_x) {
+  Batch<T> b;
+  b.rhs = 0u;
 #pragma unroll
-      for (int q = 0; q < EPL; ++q) acc.e[q] = zero_of(T{});
-      if (cur.live) {
-        for (int64_t e = cur.e0 + slice; e < cur.e1; e += 4 * (int64_t)nsl) {
-          int32_t c[4];
-          T v[4];
+  for (int u = 0; u < 4; ++u) {
+    const int64_t ee = e + (int64_t)u * sl;
+    const bool in = ee < end;
+    const int64_t ec = in ? ee : e;
+    b.c[u] = cols[ec];
+    b.v[u] = in ? neg_of(vals[ec]) : zero_of(T{});
+    if (ec >= end_x) b.rhs |= 1u << u;
+  }
+  return b;
+}
+
+// up to four L1-bypassing loads in flight, one wait: only the first `cnt` are issued (every load is an L2 request of
+// its own -- a workgroup's gathers queue at its CU's one request per clock -- so padding slots must not load)
+__device__ __forceinline__ void loadn_sc1(int cnt, const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, u32x4 &x0,
+                                          u32x4 &x1, u32x4 &x2, u32x4 &x3) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x0) : "v"(p0) : "memory");
+  if (cnt > 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x1) : "v"(p1) : "memory");
+  if (cnt > 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x2) : "v"(p2) : "memory");
+  if (cnt > 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x3) : "v"(p3) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "memory");
+}
+
+// acc -= sum over this lane's entries [e, end) (stride sl) of value * (X or, from end_x on, R)[column]; `cur` holds the
+// first batch
+template <typename T>
+__device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T> cur, int64_t e, int64_t end, int64_t end_x, int sl,
+                                           const int32_t *__restrict__ cols, const T *__restrict__ vals, const u32x4 *X, const u32x4 *R,
+                                           int ppt, int pp, int tune, Watch &watch) {
+  constexpr int EPL = PieceOf<T>::EPL;
+  while (e < end) {
+    const int64_t en = e + 4 * (int64_t)sl;
+    Batch<T> next = cur;
+    if (en < end) next = load_batch<T>(cols, vals, en, end, sl, end_x);
+    const int cnt = en <= end ? 4 : (int)((end - e + sl - 1) / sl);
+    const u32x4 *p0 = ((cur.rhs & 1u) ? R : X) + (int64_t)cur.c[0] * ppt + pp, *p1 = ((cur.rhs & 2u) ? R : X) + (int64_t)cur.c[1] * ppt + pp;
+    const u32x4 *p2 = ((cur.rhs & 4u) ? R : X) + (int64_t)cur.c[2] * ppt + pp, *p3 = ((cur.rhs & 8u) ? R : X) + (int64_t)cur.c[3] * ppt + pp;
+    typename PieceOf<T>::U x0, x1, x2, x3;
+    loadn_sc1(cnt, p0, p1, p2, p3, x0.w, x1.w, x2.w, x3.w);
+    while (!(piece_ready<T>(x0.w) && (cnt < 2 || piece_ready<T>(x1.w)) && (cnt < 3 || piece_ready<T>(x2.w)) &&
+             (cnt < 4 || piece_ready<T>(x3.w)))) {
+      if (!(tune & 2)) __builtin_amdgcn_s_sleep(1);
+      if (watch.expired()) break;
+      loadn_sc1(cnt, p0, p1, p2, p3, x0.w, x1.w, x2.w, x3.w);
+    }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int64_t ee = e + (int64_t)u * nsl;
-            const int64_t ec = ee < cur.e1 ? ee : e;       // surplus slots repeat this lane's entry with value 0
-            c[u] = cols[ec];
-            v[u] = ee < cur.e1 ? neg_of(vals[ec]) : zero_of(T{});
+    for (int q = 0; q < EPL; ++q) {
+      fma_acc(acc.e[q], cur.v[0], x0.e[q]);
+      if (cnt > 1) fma_acc(acc.e[q], cur.v[1], x1.e[q]);
+      if (cnt > 2) fma_acc(acc.e[q], cur.v[2], x2.e[q]);
+      if (cnt > 3) fma_acc(acc.e[q], cur.v[3], x3.e[q]);
+    }
+    cur = next;
+    e = en;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ typename PieceOf<T>::U add_pieces(typename PieceOf<T>::U a, typename PieceOf<T>::U b) {
+#pragma unroll
+  for (int q = 0; q < PieceOf<T>::EPL; ++q) a.e[q] = add_of(a.e[q], b.e[q]);
+  return a;
+}
+template <int CTRL, typename PU> __device__ __forceinline__ PU dpp_piece(PU a) {
+  PU t;
+  t.w.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.w.x, CTRL, 0xF, 0xF, false);
+  t.w.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.w.y, CTRL, 0xF, 0xF, false);
+  t.w.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.w.z, CTRL, 0xF, 0xF, false);
+  t.w.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a.w.w, CTRL, 0xF, 0xF, false);
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
+  constexpr int EPL = PieceOf<T>::EPL;
+  using PU = typename PieceOf<T>::U;
+  __shared__ int s_pick[2];
+  __shared__ __attribute__((aligned(16))) u32x4 s_red[4 * 64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  Watch watch{a.ctrl, a.err_host, (unsigned long long)wall_clock64(), 0u, false};
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & (kMaxXcd - 1);   // HW_REG_XCC_ID
+  unsigned *const queues = a.ctrl + kCtrlHead + kMaxXcd * (a.ngroups + 1);
+  unsigned *const flags = queues + 32 * a.ngroups;
+  for (int round = 0; round <= a.ngroups; ++round) {
+    if (tid == 0) s_pick[0] = claim_group(a.ctrl, xcc, round, a.ngroups, watch);
+    __syncthreads();
+    const int g = s_pick[0];
+    __syncthreads();
+    if (g < 0) break;
+    unsigned *const qhead = queues + 32 * g;
+    unsigned *const done = flags + (int64_t)g * a.done_stride;
+    if (tid == 0) s_pick[0] = (int)__hip_atomic_fetch_add(qhead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int it = 0;; ++it) {
+      const int U = s_pick[it & 1];
+      if (U >= a.total_units || U < 0) break;
+      // the NEXT unit is taken now: the atomic's round trip hides behind this unit (a workgroup works through its
+      // units in ascending order, so the oldest unfinished unit is always somebody's current one)
+      if (tid == 0) s_pick[(it + 1) & 1] = (int)__hip_atomic_fetch_add(qhead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int k = 0;
+      while (k + 1 < a.nops && U >= a.op[k + 1].unit0) ++k;
+      const TrsvOp &o = a.op[k];
+      const TrsvUnit ud = o.units[U - o.unit0];
+      unsigned long long *const stamp = (a.trace && g == 0 && tid == 0) ? a.trace + (int64_t)U * 16 : nullptr;
+      if (stamp) stamp[0] = wall_clock64();
+      const int lg = ud.lg_lr, lr = 1 << lg;                  // lanes per row
+      const int PL = a.pl < lr ? a.pl : lr;                    // lanes across the pieces of a row
+      const int sl = lr / PL;                                  // slices across its entries
+      const int l = tid & (lr - 1);
+      const int pl = l & (PL - 1), slice = l / PL;
+      const int row_slot = tid >> lg;
+      const bool live = row_slot < (int)ud.nr;
+      const int64_t p = ud.p0 + (live ? row_slot : 0);
+      const TrsvRow rd = o.rows[p];
+      const int64_t r = o.lev_rows[p];
+      const int32_t *__restrict__ cols = o.cols;
+      const T *__restrict__ vals = (const T *)o.vals;
+      const int ppt = a.ppt;
+      const u32x4 *rhs = a.scratch + ((int64_t)k * a.ngroups + g) * a.n8 * ppt;
+      u32x4 *X = a.scratch + ((int64_t)(k + 1) * a.ngroups + g) * a.n8 * ppt;
+      const int64_t e_far = rd.e0 + slice, end_far = rd.e0 + rd.nfar;
+      const int64_t e_near = end_far + slice, end_x = end_far + rd.nnear, end_all = end_x + rd.nrhs;
+      bool first = true;
+      for (int pp0 = 0; pp0 < ppt; pp0 += PL) {               // (one trip unless a group holds more than 64 pieces of a row)
+        const int pq = pp0 + pl;
+        const bool work = live && pq < ppt;
+        const int pp = pq < ppt ? pq : ppt - 1;
+        PU acc;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) acc.e[q] = zero_of(T{});
+        Batch<T> bf, bn;
+        if (work && e_far < end_far) bf = load_batch<T>(cols, vals, e_far, end_far, sl, end_far);
+        if (work && e_near < end_all) bn = load_batch<T>(cols, vals, e_near, end_all, sl, end_x);
+        const bool owner = work && slice == 0;
+        if (owner && !(a.tune & 8)) {
+          // the line this row's result will be stored into, brought into the L2 now: a consumer's poll of a line the L2
+          // holds only the freshly stored bytes of would go to memory for the rest of it
+          const u32x4 warm = load_sc1(X + r * ppt + pp);
+          asm volatile("" :: "v"(warm));
+        }
+        if (first) {                                           // the far entries: dependencies at least kNearWindow units back
+          if (stamp) stamp[1] = wall_clock64();
+          if (tid == 0) wait_unit(done, ud.far_unit < 0 ? -1 : o.unit0 + ud.far_unit, watch);
+          __syncthreads();
+          if (stamp) stamp[2] = wall_clock64();
+        }
+        if (work) accumulate<T>(acc, bf, e_far, end_far, end_far, sl, cols, vals, X, rhs, ppt, pp, a.tune, watch);
+        if (first) {
+          // the near entries are polled piece by piece, which only the units next to the front may do: wait for the unit
+          // kNearWindow back (units finish roughly in order; what is still missing then is polled for)
+          if (stamp) stamp[3] = wall_clock64();
+          if (tid == 0 && ud.near_unit > ud.far_unit && ud.thr_unit >= 0) wait_unit(done, o.unit0 + ud.thr_unit, watch);
+          __syncthreads();
+          if (stamp) stamp[4] = wall_clock64();
+        }
+        if (work) accumulate<T>(acc, bn, e_near, end_all, end_x, sl, cols, vals, X, rhs, ppt, pp, a.tune, watch);
+        if (first && stamp) stamp[5] = wall_clock64();
+        first = false;
+        // sum of the slices of a row: lanes PL apart inside a wave, then (rows wider than a wave) through the LDS
+        {
+          const int top = lr < 64 ? lr : 64;
+          int off = PL;
+          if (PL == 1 && !(a.tune & 4)) {
+            // adjacent lanes: the first four steps are data-parallel-primitive moves inside a row of 16 lanes (no LDS
+            // crossbar round trip per step): pairs, quads (quad_perm), the two quads of a half (row_half_mirror),
+            // the two halves (row_mirror) -- any pairing of distinct partial sums will do for a sum
+            if (top > 1) { acc = add_pieces<T>(acc, dpp_piece<0xB1>(acc)); off = 2; }     // quad_perm [1,0,3,2]
+            if (top > 2) { acc = add_pieces<T>(acc, dpp_piece<0x4E>(acc)); off = 4; }     // quad_perm [2,3,0,1]
+            if (top > 4) { acc = add_pieces<T>(acc, dpp_piece<0x141>(acc)); off = 8; }    // row_half_mirror
+            if (top > 8) { acc = add_pieces<T>(acc, dpp_piece<0x140>(acc)); off = 16; }   // row_mirror
           }
-          P x[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const P *>(W + (int64_t)c[u] * ldw + pc * EPL);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < EPL; ++q) fma_acc(acc.e[q], v[u], x[u].e[q]);
+          for (; off < top; off <<= 1) {
+            PU t;
+            t.w.x = __shfl_xor(acc.w.x, off); t.w.y = __shfl_xor(acc.w.y, off);
+            t.w.z = __shfl_xor(acc.w.z, off); t.w.w = __shfl_xor(acc.w.w, off);
+            acc = add_pieces<T>(acc, t);
+          }
         }
+        if (lr > 64) {                                         // (workgroup-uniform)
+          if (lane < PL) s_red[wave * 64 + lane] = acc.w;
+          __syncthreads();
+          if (l < PL) {
+            PU tot;
+            tot.w = s_red[wave * 64 + lane];
+            for (int wv = 1; wv < (lr >> 6); ++wv) {
+              PU t;
+              t.w = s_red[(wave + wv) * 64 + lane];
+#pragma unroll
+              for (int q = 0; q < EPL; ++q) tot.e[q] = add_of(tot.e[q], t.e[q]);
+            }
+            acc = tot;
+          }
+          __syncthreads();
+        }
+        if (stamp && pp0 == 0) stamp[8] = wall_clock64();
+        if (owner) X[r * ppt + pp] = piece_clean<T>(acc.w);
+        if (stamp && pp0 == 0) stamp[9] = wall_clock64();
       }
-      if (LPR < 64) reduce_slices<T, EPL>(acc, LPR, 64 / LPR);
-      if ((tid & 63) < LPR) s_red[(tid >> 6) * LPR + (tid & 63)] = acc;
-      __syncthreads();
-      if (cur.live && l < LPR && piece < ppr) {
-        T *wr = W + cur.r * ldw + piece * EPL;
-        P tot = *reinterpret_cast<const P *>(wr);
-        const int w0 = (tid - l) >> 6;                     // first wave of this row
-        for (int wv = 0; wv < wl / 64; ++wv) {
-          const P part = s_red[(w0 + wv) * LPR + piece];
-#pragma unroll
-          for (int q = 0; q < EPL; ++q) tot.e[q] = add_of(tot.e[q], part.e[q]);
-        }
-        if (dinv) {
-          const T d = dinv[cur.pos];
-#pragma unroll
-          for (int q = 0; q < EPL; ++q) tot.e[q] = mul_of(tot.e[q], d);
-        }
-        *reinterpret_cast<P *>(wr) = tot;
-      }
+      // every wave has ISSUED its stores (the done word is a hint: it need not wait for them to land), and the next
+      // pick is in the LDS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (stamp) stamp[10] = wall_clock64();
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) *(volatile unsigned *)(done + U) = 1u;
+      if (stamp) { stamp[6] = wall_clock64(); stamp[7] = ((unsigned long long)(unsigned)(o.unit0 + ud.near_unit) << 32) | (xcc << 24) | (unsigned)blockIdx.x; }
     }
     __syncthreads();
   }
 }
 
-// a level of at most this many (row, lane) tasks counts as small (RLH_SPTRSV_CHAIN_TASKS: tunable)
-static int64_t chain_tasks() {
-  const char *e = getenv("RLH_SPTRSV_CHAIN_TASKS");
-  return (e && *e) ? atoll(e) : 512;
-}
-
-// slices per row: enough lanes that a lane walks about four entries, within one wave
-static int slices_for(const rlh_sptrsv *t, int lpr) {
-  const double avg = t->n > 0 ? (double)t->nnz / (double)t->n : 0.0;
-  int sl = 1;
-  while (sl * 4 < avg && sl * 2 * lpr <= 64) sl *= 2;
-  const char *e = getenv("RLH_SPTRSV_SLICES");             // tunable
-  if (e && *e && atoi(e) > 0) {
-    sl = 1;
-    while (sl * 2 <= atoi(e) && sl * 2 * lpr <= 64) sl *= 2;
-  }
-  return sl;
-}
-
-template <typename T, int LPR>
-static void launch_levels_lpr(hipStream_t s, const rlh_sptrsv *t, T *W, int ldw, int ppr) {
-  const int64_t nl = (int64_t)t->lev_off.size() - 1;
-  const int sl = slices_for(t, LPR);
-  const int64_t lpt = (int64_t)LPR * sl;
-  int64_t lev = 0;
-  while (lev < nl) {
-    const int64_t nrows = t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev];
-    if (nrows * lpt > chain_tasks()) {
-      const int64_t threads = nrows * lpt;
-      hipLaunchKernelGGL((trsv_level_kernel<T, LPR>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
-                         t->lev_rows, t->lev_off[(size_t)lev], (int)nrows, sl, t->rowptr, t->cols, (const T *)t->vals,
-                         (const T *)t->dinv, W, ldw, ppr);
-      ++lev;
-      continue;
+// right-hand side into slot 0 (row r of the scratch = row perm[r] of B, columns >= m zero), the pattern into every result slot
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_scatter_in(const T *__restrict__ B, int64_t ldb, const int64_t *__restrict__ perm,
+                                                       u32x4 *__restrict__ scratch, int64_t n, int64_t n8, int m, int ngroups, int ppt,
+                                                       int nslots) {
+  constexpr int EPL = PieceOf<T>::EPL;
+  const int64_t total = n8 * ngroups * ppt;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t r = t % n8;                                    // rows fastest: coalesced reads of B's columns
+  const int64_t gq = t / n8;
+  const int q = (int)(gq % ppt), g = (int)(gq / ppt);
+  const int64_t dst = ((int64_t)g * n8 + r) * ppt + q;
+  typename PieceOf<T>::U out;
+  if (r < n) {
+    const int64_t src = perm ? perm[r] : r;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int v = (g * ppt + q) * EPL + e;
+      out.e[e] = v < m ? B[src + (int64_t)v * ldb] : zero_of(T{});
     }
-    int64_t end = lev + 1;                    // the run of small levels starting here
-    while (end < nl && end - lev < kChainLevels &&
-           (t->lev_off[(size_t)end + 1] - t->lev_off[(size_t)end]) * lpt <= chain_tasks()) ++end;
-    hipLaunchKernelGGL((trsv_chain_kernel<T, LPR>), dim3(1), dim3(1024), 0, s, t->lev_rows, t->lev_off_d, (int)lev, (int)end, sl,
-                       t->rowptr, t->cols, (const T *)t->vals, (const T *)t->dinv, W, ldw, ppr);
-    lev = end;
+    out.w = piece_clean<T>(out.w);
+  } else {
+    out.w = u32x4{0u, 0u, 0u, 0u};
   }
+  scratch[dst] = out.w;
+  const u32x4 pattern = {kSentinel, kSentinel, kSentinel, kSentinel};
+  const int64_t slot = (int64_t)ngroups * n8 * ppt;
+  for (int k = 1; k < nslots; ++k) scratch[k * slot + dst] = pattern;
 }
 
 template <typename T>
-static void launch_levels(hipStream_t s, const rlh_sptrsv *t, T *W, int ldw, int ppr) {
-  int lpr = 1;
-  while (lpr < ppr && lpr < 64) lpr *= 2;
-  switch (lpr) {
-    case 1: launch_levels_lpr<T, 1>(s, t, W, ldw, ppr); break;
-    case 2: launch_levels_lpr<T, 2>(s, t, W, ldw, ppr); break;
-    case 4: launch_levels_lpr<T, 4>(s, t, W, ldw, ppr); break;
-    case 8: launch_levels_lpr<T, 8>(s, t, W, ldw, ppr); break;
-    case 16: launch_levels_lpr<T, 16>(s, t, W, ldw, ppr); break;
-    case 32: launch_levels_lpr<T, 32>(s, t, W, ldw, ppr); break;
-    default: launch_levels_lpr<T, 64>(s, t, W, ldw, ppr); break;
+__global__ __launch_bounds__(256) void trsv_gather_out(const u32x4 *__restrict__ res, const int64_t *__restrict__ perm, T *__restrict__ X,
+                                                       int64_t ldx, int64_t n, int64_t n8, int m, int ngroups, int ppt) {
+  constexpr int EPL = PieceOf<T>::EPL;
+  const int64_t total = n * ngroups * ppt;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t r = t % n;
+  const int64_t gq = t / n;
+  const int q = (int)(gq % ppt), g = (int)(gq / ppt);
+  typename PieceOf<T>::U in;
+  in.w = res[((int64_t)g * n8 + r) * ppt + q];
+  const int64_t dst = perm ? perm[r] : r;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int v = (g * ppt + q) * EPL + e;
+    if (v < m) X[dst + (int64_t)v * ldx] = in.e[e];
   }
 }
 
-// number of kernel launches launch_levels issues for an operator
-static int64_t count_launches(const rlh_sptrsv *t, int lpr) {
-  lpr *= slices_for(t, lpr);
-  const int64_t nl = (int64_t)t->lev_off.size() - 1;
-  int64_t n = 0, lev = 0;
-  while (lev < nl) {
-    ++n;
-    if ((t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr > chain_tasks()) { ++lev; continue; }
-    const int64_t first = lev++;
-    while (lev < nl && lev - first < kChainLevels && (t->lev_off[(size_t)lev + 1] - t->lev_off[(size_t)lev]) * lpr <= chain_tasks()) ++lev;
+// ------------------------------------------------------------------ host side: plans and the launch
+static int pow2_ceil(int64_t v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// Units, far / near split and wait words of one operator for PL lanes across the pieces of a row.
+static int build_plan(rlh_sptrsv *t, int pl, TrsvPlan *plan) {
+  const int64_t n = t->n;
+  const int64_t nlev = (int64_t)t->lev_off.size() - 1;
+  std::vector<TrsvUnit> units;
+  std::vector<int32_t> unit_of((size_t)n);
+  std::vector<int32_t> last_unit_of_level((size_t)nlev, -1), level_of_unit;
+  for (int64_t lev = 0; lev < nlev; ++lev) {
+    const int64_t p0 = t->lev_off[(size_t)lev], p1 = t->lev_off[(size_t)lev + 1];
+    const int64_t nrows = p1 - p0;
+    if (nrows == 0) continue;
+    int64_t longest = 0;
+    for (int64_t q = p0; q < p1; ++q) longest = std::max(longest, t->rowptr_h[(size_t)q + 1] - t->rowptr_h[(size_t)q]);
+    // at most four entries per lane -- ONE batch, whose column indices and values are in registers before the
+    // unit starts to wait: a second batch would fetch them on the critical path
+    int sl = pow2_ceil((longest + 3) / 4);
+    if (sl > 256 / pl) sl = 256 / pl;
+    if (sl < 1) sl = 1;
+    const int lr = pl * sl;
+    const int64_t cap = 256 / lr;                              // rows per unit
+    const int64_t nu = (nrows + cap - 1) / cap;
+    int lg = 0;
+    while ((1 << lg) < lr) ++lg;
+    int64_t p = p0;
+    for (int64_t u = 0; u < nu; ++u) {                         // the rows of a level dealt evenly to its units
+      const int64_t cnt = nrows / nu + (u < nrows % nu ? 1 : 0);
+      TrsvUnit d;
+      memset(&d, 0, sizeof(d));
+      d.p0 = (int32_t)p; d.nr = (uint16_t)cnt; d.lg_lr = (uint8_t)lg; d.far_unit = -1; d.near_unit = -1; d.thr_unit = -1;
+      level_of_unit.push_back((int32_t)lev);
+      for (int64_t q = p; q < p + cnt; ++q) unit_of[(size_t)q] = (int32_t)units.size();
+      units.push_back(d);
+      p += cnt;
+    }
+    last_unit_of_level[(size_t)lev] = (int32_t)units.size() - 1;
   }
-  return n;
+  // FAR entries of a unit of level L: what lies at least two levels AND kNearWindow units back -- gathered when the
+  // last of those units is done, long before the unit's turn; the rest (the level before, and whatever is close in the
+  // queue) is polled for once that boundary unit is done, by about a level's worth of units at a time
+  for (size_t u = 0; u < units.size(); ++u) {
+    const int32_t lev = level_of_unit[u];
+    int32_t thr = (int32_t)u - kNearWindow;
+    if (lev >= 2) thr = std::min(thr, last_unit_of_level[(size_t)lev - 2]); else thr = -1;
+    units[u].thr_unit = thr < 0 ? -1 : thr;
+  }
+  RLH_REQUIRE(units.size() < ((size_t)1 << 30), "rlh_sptrsv: too many units");
+  std::vector<TrsvRow> rows((size_t)std::max<int64_t>(n, 1));
+  for (int64_t p = 0; p < n; ++p) {
+    const int64_t e0 = t->rowptr_h[(size_t)p], e1 = t->rowptr_h[(size_t)p + 1], ex = e0 + t->nx_h[(size_t)p];
+    const int32_t u = unit_of[(size_t)p];
+    TrsvUnit &d = units[(size_t)u];
+    // the x entries of a row are sorted by the position of the row they read: its far entries are a prefix
+    int64_t nfar = 0;
+    while (e0 + nfar < ex && unit_of[(size_t)t->dep_pos_h[(size_t)(e0 + nfar)]] <= d.thr_unit) ++nfar;
+    if (nfar > 0) d.far_unit = std::max(d.far_unit, unit_of[(size_t)t->dep_pos_h[(size_t)(e0 + nfar - 1)]]);
+    if (ex > e0) d.near_unit = std::max(d.near_unit, unit_of[(size_t)t->dep_pos_h[(size_t)(ex - 1)]]);
+    RLH_REQUIRE(ex - e0 - nfar < 65536 && e1 - ex < 65536, "rlh_sptrsv: a row has too many near entries");
+    rows[(size_t)p] = TrsvRow{e0, (int32_t)nfar, (uint16_t)(ex - e0 - nfar), (uint16_t)(e1 - ex)};
+  }
+  plan->pl = pl;
+  plan->nunits = (int64_t)units.size();
+  RLH_HIP(hipMalloc((void **)&plan->units, std::max<size_t>(units.size(), 1) * sizeof(TrsvUnit)));
+  RLH_HIP(hipMalloc((void **)&plan->rows, rows.size() * sizeof(TrsvRow)));
+  if (!units.empty()) RLH_HIP(hipMemcpy(plan->units, units.data(), units.size() * sizeof(TrsvUnit), hipMemcpyHostToDevice));
+  RLH_HIP(hipMemcpy(plan->rows, rows.data(), rows.size() * sizeof(TrsvRow), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static void free_plan(TrsvPlan *p) {
+  if (p->units) (void)hipFree(p->units);
+  if (p->rows) (void)hipFree(p->rows);
+  p->units = nullptr; p->rows = nullptr; p->pl = 0; p->nunits = 0;
+}
+
+static int plan_for(rlh_sptrsv *t, int pl, TrsvPlan **out) {
+  for (int i = 0; i < 2; ++i)
+    if (t->plan[i].pl == pl) { t->plan_lru = i; *out = &t->plan[i]; return 0; }
+  const int victim = t->plan[0].pl == 0 ? 0 : (t->plan[1].pl == 0 ? 1 : 1 - t->plan_lru);
+  if (t->plan[victim].pl) {
+    RLH_HIP(hipStreamSynchronize(ctx().stream));
+    free_plan(&t->plan[victim]);
+  }
+  if (int rc = build_plan(t, pl, &t->plan[victim])) { free_plan(&t->plan[victim]); return rc; }
+  t->plan_lru = victim;
+  *out = &t->plan[victim];
+  return 0;
 }
 
 template <int DT>
@@ -478,73 +704,127 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
   using T = typename DType<DT>::T;
   constexpr int EPL = 16 / (int)sizeof(T);
   Context &c = ctx();
+  if (int rc = check_async_error()) return rc;
   rlh_sptrsv *head = ops[0];
   const int64_t n = head->n;
-  const int ppr = (int)((m + EPL - 1) / EPL);
-  const int ldw = ppr * EPL;
-  const int64_t need = n * ldw * (int64_t)sizeof(T);
+  const int64_t n8 = (n + 7) & ~(int64_t)7;
+  const int64_t pieces = (m + EPL - 1) / EPL;
+  const int ngroups = (int)std::min<int64_t>(pieces, kMaxXcd);
+  const int ppt = (int)((pieces + ngroups - 1) / ngroups);
+  const int pl = std::min(pow2_ceil(ppt), 64);
+  TrsvArgs a;
+  memset(&a, 0, sizeof(a));
+  int64_t total_units = 0;
+  for (int i = 0; i < nops; ++i) {
+    TrsvPlan *plan = nullptr;
+    if (int rc = plan_for(ops[i], pl, &plan)) return rc;
+    a.op[i].units = plan->units; a.op[i].rows = plan->rows; a.op[i].lev_rows = ops[i]->lev_rows; a.op[i].cols = ops[i]->cols;
+    a.op[i].vals = ops[i]->vals;
+    a.op[i].unit0 = (int32_t)total_units; a.op[i].nunits = (int32_t)plan->nunits;
+    total_units += plan->nunits;
+  }
+  RLH_REQUIRE(total_units < ((int64_t)1 << 30), "rlh_sptrsv_solve_chain: too many units");
+  const int64_t done_stride = (total_units + 31) & ~(int64_t)31;
+  const int64_t ctrl_words = kCtrlHead + kMaxXcd * (ngroups + 1) + 32 * (int64_t)ngroups + (int64_t)ngroups * done_stride;
+  const int64_t ctrl_bytes = ((ctrl_words * 4 + 15) / 16) * 16;
+  const int64_t slot_pieces = (int64_t)ngroups * n8 * ppt;
+  const int64_t scratch_bytes = (int64_t)(nops + 1) * slot_pieces * 16;
+  const int64_t need = ctrl_bytes + scratch_bytes;
   if (head->work_bytes < need) {
     RLH_HIP(hipStreamSynchronize(c.stream));
     if (head->work) RLH_HIP(hipFree(head->work));
     head->work = nullptr; head->work_bytes = 0;
-    if (head->graph) { (void)hipGraphExecDestroy(head->graph); head->graph = nullptr; }
     RLH_HIP(hipMalloc(&head->work, (size_t)need));
     head->work_bytes = need;
   }
-  T *W = (T *)head->work;
-  int64_t nb = (n * ppr + 255) / 256;
-  if (nb > (int64_t)c.num_cu * 16) nb = (int64_t)c.num_cu * 16;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((trsv_transpose_in<T>), dim3((unsigned)nb), dim3(256), 0, c.stream, (const T *)B_, ldb, perm_in, W, ldw, n,
-                     (int)m);
-  RLH_HIP(hipGetLastError());
-  // the level launches depend only on (operators, m, scratch): captured once, replayed afterwards
-  uint64_t key = (uint64_t)m * 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < nops; ++i) key = (key ^ (uint64_t)(uintptr_t)ops[i]) * 0xBF58476D1CE4E5B9ull;
-  key ^= (uint64_t)(uintptr_t)c.stream;
-  int64_t launches = 0;
-  {
-    int lpr = 1;
-    while (lpr < ppr && lpr < 64) lpr *= 2;
-    for (int i = 0; i < nops; ++i) launches += count_launches(ops[i], lpr);
+  a.nops = nops; a.total_units = (int)total_units; a.ngroups = ngroups; a.ppt = ppt; a.pl = pl; a.done_stride = (int)done_stride;
+  a.n8 = n8;
+  a.ctrl = (unsigned *)head->work;                            // (the control words open the allocation: zeroed per call)
+  a.scratch = (u32x4 *)((char *)head->work + ctrl_bytes);
+  a.err_host = c.async_err_d;
+  { const char *e = getenv("RLH_SPTRSV_TUNE"); a.tune = (e && *e) ? atoi(e) : 0; }      // experiments (see tools/trsv_run.sh)
+  const char *trace_path = getenv("RLH_SPTRSV_TRACE");      // diagnostics: per-unit stamps of group 0 to this file (synchronises)
+  if (trace_path && *trace_path) {
+    RLH_HIP(hipMalloc((void **)&a.trace, (size_t)total_units * 128));
+    RLH_HIP(hipMemsetAsync(a.trace, 0, (size_t)total_units * 128, c.stream));
   }
-  // (plain launches under rocprofv3 -- ROCP_TOOL_LIBRARIES is its tool library -- whose kernel tracing segfaults inside
-  // hipGraphLaunch on graphs of this many nodes: a profiled run of bench.py or the tests must not die there)
-  const bool use_graph = launches >= 8 && !getenv("RLH_SPTRSV_NO_GRAPH") && !getenv("ROCP_TOOL_LIBRARIES");
-  if (use_graph) {
-    if (!head->graph || head->graph_key != key) {
-      if (head->graph) { (void)hipGraphExecDestroy(head->graph); head->graph = nullptr; }
-      hipGraph_t g = nullptr;
-      RLH_HIP(hipStreamBeginCapture(c.stream, hipStreamCaptureModeThreadLocal));
-      for (int i = 0; i < nops; ++i) launch_levels<T>(c.stream, ops[i], W, ldw, ppr);
-      RLH_HIP(hipStreamEndCapture(c.stream, &g));
-      RLH_HIP(hipGraphInstantiate(&head->graph, g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
-      head->graph_key = key;
-    }
-    RLH_HIP(hipGraphLaunch(head->graph, c.stream));
-  } else {
-    for (int i = 0; i < nops; ++i) launch_levels<T>(c.stream, ops[i], W, ldw, ppr);
+  RLH_HIP(hipMemsetAsync(head->work, 0, (size_t)ctrl_bytes, c.stream));
+  {
+    const int64_t nb = (slot_pieces + 255) / 256;
+    RLH_REQUIRE(nb < ((int64_t)1 << 31), "rlh_sptrsv_solve_chain: block too large");
+    hipLaunchKernelGGL((trsv_scatter_in<T>), dim3((unsigned)nb), dim3(256), 0, c.stream, (const T *)B_, ldb, perm_in, a.scratch, n, n8,
+                       (int)m, ngroups, ppt, nops + 1);
     RLH_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL((trsv_transpose_out<T>), dim3((unsigned)nb), dim3(256), 0, c.stream, (const T *)W, ldw, perm_out, (T *)X_, ldx,
-                     n, (int)m);
-  RLH_HIP(hipGetLastError());
+  {
+    int occ = 0;                                               // resident workgroups per CU of this kernel
+    RLH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trsv_pipeline_kernel<T>, 256, 0));
+    int per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+    const char *e = getenv("RLH_SPTRSV_WG_PER_CU");            // tunable
+    if (e && *e && atoi(e) > 0) per_cu = atoi(e);
+    int64_t grid = (int64_t)c.num_cu * per_cu;
+    const int64_t most = total_units * ngroups + kMaxXcd;      // (no more workgroups than units to take)
+    if (grid > most) grid = most;
+    if (grid < kMaxXcd) grid = kMaxXcd;
+    hipLaunchKernelGGL((trsv_pipeline_kernel<T>), dim3((unsigned)grid), dim3(256), 0, c.stream, a);
+    RLH_HIP(hipGetLastError());
+  }
+  {
+    const int64_t nb = (n * ngroups * ppt + 255) / 256;
+    hipLaunchKernelGGL((trsv_gather_out<T>), dim3((unsigned)nb), dim3(256), 0, c.stream,
+                       (const u32x4 *)(a.scratch + (int64_t)nops * slot_pieces), perm_out, (T *)X_, ldx, n, n8, (int)m, ngroups, ppt);
+    RLH_HIP(hipGetLastError());
+  }
+  if (a.trace) {
+    std::vector<unsigned long long> h((size_t)total_units * 16);
+    RLH_HIP(hipStreamSynchronize(c.stream));
+    RLH_HIP(hipMemcpy(h.data(), a.trace, h.size() * 8, hipMemcpyDeviceToHost));
+    RLH_HIP(hipFree(a.trace));
+    if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+  }
   return 0;
 }
 
+// host arithmetic of the block transform: double / complex double whatever the factor's type
+template <int DT> struct HostOf { using H = double; };
+template <> struct HostOf<RLH_C> { using H = std::complex<double>; };
+template <> struct HostOf<RLH_Z> { using H = std::complex<double>; };
+static inline double to_h(float v) { return v; }
+static inline double to_h(double v) { return v; }
+static inline std::complex<double> to_h(c32 v) { return {v.re, v.im}; }
+static inline std::complex<double> to_h(c64 v) { return {v.re, v.im}; }
+static inline void from_h(double h, float &v) { v = (float)h; }
+static inline void from_h(double h, double &v) { v = h; }
+static inline void from_h(const std::complex<double> &h, c32 &v) { v = c32{(float)h.real(), (float)h.imag()}; }
+static inline void from_h(const std::complex<double> &h, c64 &v) { v = c64{h.real(), h.imag()}; }
+
+// rows per diagonal block of the transform below (RLH_SPTRSV_BLOCK: 1 switches it off)
+static int block_limit() {
+  const char *e = getenv("RLH_SPTRSV_BLOCK");
+  int b = (e && *e) ? atoi(e) : 8;
+  return b < 1 ? 1 : (b > 16 ? 16 : b);
+}
+
+// Turns the triangular factor T into the operator the device applies.
+//
+// BLOCK TRANSFORM.  A chain of consecutive rows that each read the one before (the degrees of freedom of a
+// finite-element node, the rows of a supernode of a direct factor) is one dependency level per row.  With D the
+// (small, triangular) diagonal block of such a chain, T x = b is D^-1 T x = D^-1 b, and D^-1 T has an identity
+// diagonal block: the rows of the chain no longer read each other, at the price of every row reading the union
+// of the chain's earlier off-block patterns (rows of one node or supernode share their pattern: 10-30 % more
+// entries for 4-5 times fewer levels on the FE factors).  Chains are grown greedily in solve order, up to
+// block_limit() rows, while the entry count stays within 30 % of the original.  Every row becomes
+//     x_r = sum_k w_k rhs[r_k]  -  sum_j m_j x_j
+// with the rhs entries (the row of D^-1; a single 1 / diagonal for an unblocked row) stored behind the x entries:
+// the inverse diagonal is folded into the values and no row needs a division.
 template <int DT>
 static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *indices, const void *values_) {
   using T = typename DType<DT>::T;
+  using H = typename HostOf<DT>::H;
   const T *values = (const T *)values_;
   const int64_t n = t->n;
-  std::vector<int64_t> rp((size_t)n + 1, 0);
-  std::vector<int32_t> cols;
-  std::vector<T> vals, dinv;
-  if (!t->unit) dinv.resize((size_t)n);
-  std::vector<int32_t> level((size_t)n, 0);
-  cols.reserve((size_t)(indptr[n] - indptr[0]));
-  vals.reserve((size_t)(indptr[n] - indptr[0]));
+  std::vector<H> diag((size_t)n, H(1.0));
+  int64_t nstrict = 0;
   for (int64_t i = 0; i < n; ++i) {
     bool have_diag = false;
     for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
@@ -552,39 +832,149 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
       RLH_REQUIRE(j >= 0 && j < n, "rlh_sptrsv_create: column index out of range in row %lld", (long long)i);
       if (j == i) {
         RLH_REQUIRE(!t->unit, "rlh_sptrsv_create: a unit-diagonal factor must not store its diagonal (row %lld)", (long long)i);
-        const T d = values[e];
-        double re, im;
-        if constexpr (DType<DT>::cplx) { re = d.re; im = d.im; } else { re = d; im = 0.0; }
-        const double a2 = re * re + im * im;
-        RLH_REQUIRE(a2 > 0.0, "rlh_sptrsv_create: zero diagonal in row %lld", (long long)i);
-        if constexpr (DType<DT>::cplx) dinv[(size_t)i] = T{(decltype(d.re))(re / a2), (decltype(d.re))(-im / a2)};
-        else dinv[(size_t)i] = (T)(1.0 / re);
+        RLH_REQUIRE(!have_diag, "rlh_sptrsv_create: row %lld stores its diagonal twice", (long long)i);
+        diag[(size_t)i] = to_h(values[e]);
+        RLH_REQUIRE(std::abs(diag[(size_t)i]) > 0.0, "rlh_sptrsv_create: zero diagonal in row %lld", (long long)i);
         have_diag = true;
       } else {
         RLH_REQUIRE(t->lower ? j < i : j > i, "rlh_sptrsv_create: entry (%lld, %d) lies in the wrong triangle", (long long)i, j);
-        cols.push_back(j);
-        vals.push_back(values[e]);
+        ++nstrict;
       }
     }
     RLH_REQUIRE(t->unit || have_diag, "rlh_sptrsv_create: row %lld has no diagonal entry", (long long)i);
-    rp[(size_t)i + 1] = (int64_t)cols.size();
   }
-  // dependency levels
-  int32_t nlev = 0;
-  if (t->lower) {
+  t->nnz = nstrict;
+  auto row_at = [&](int64_t s) -> int64_t { return t->lower ? s : n - 1 - s; };      // solve order
+  // ---- the transformed rows: x entries (column, m) then rhs entries (row, -w), per ORIGINAL row
+  std::vector<int64_t> rp((size_t)n + 1, 0);
+  std::vector<int32_t> nx((size_t)n, 0);
+  std::vector<int32_t> cols;
+  std::vector<T> vals;
+  cols.reserve((size_t)nstrict + (size_t)n);
+  vals.reserve((size_t)nstrict + (size_t)n);
+  {
+    const int B = block_limit();
+    const double fmax = 0.3;
+    std::vector<int64_t> seen((size_t)n, -1), member((size_t)n, -1);
+    std::vector<int32_t> local((size_t)n, 0);
+    std::vector<H> wv((size_t)n, H(0.0));
+    std::vector<int32_t> touched;
+    std::vector<H> D, W;
+    // rows are produced in solve order; their entries are parked per block and copied out by row afterwards
+    std::vector<std::vector<int32_t>> bc((size_t)B);
+    std::vector<std::vector<T>> bv((size_t)B);
+    std::vector<int64_t> row_start((size_t)n, 0), row_len((size_t)n, 0);
+    std::vector<int32_t> pc;                       // parked columns / values of all rows, in production order
+    std::vector<T> pv;
+    pc.reserve((size_t)nstrict + (size_t)n);
+    pv.reserve((size_t)nstrict + (size_t)n);
+    int64_t s = 0, nb = 0;
+    while (s < n) {
+      // grow the chain
+      const int64_t r0 = row_at(s);
+      member[(size_t)r0] = nb; local[(size_t)r0] = 0;
+      int64_t acc = 0, old_total = 0, new_total = 0;
+      for (int64_t e = indptr[r0]; e < indptr[r0 + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (j == r0) continue;
+        if (seen[(size_t)j] != nb) { seen[(size_t)j] = nb; ++acc; }
+        ++old_total;
+      }
+      new_total = acc + 1;
+      int k = 1;
+      while (k < B && s + k < n) {
+        const int64_t rj = row_at(s + k), rprev = row_at(s + k - 1);
+        bool chained = false;
+        int64_t fresh = 0, cnt = 0;
+        for (int64_t e = indptr[rj]; e < indptr[rj + 1]; ++e) {
+          const int32_t j = indices[e];
+          if (j == rj) continue;
+          ++cnt;
+          if (j == rprev) chained = true;
+          if (member[(size_t)j] != nb && seen[(size_t)j] != nb) ++fresh;
+        }
+        if (!chained) break;
+        const int64_t old2 = old_total + cnt, new2 = new_total + acc + fresh + (k + 1);
+        if ((double)new2 > (1.0 + fmax) * (double)old2 + 8.0) break;
+        for (int64_t e = indptr[rj]; e < indptr[rj + 1]; ++e) {
+          const int32_t j = indices[e];
+          if (j != rj && member[(size_t)j] != nb) seen[(size_t)j] = nb;
+        }
+        member[(size_t)rj] = nb; local[(size_t)rj] = k;
+        acc += fresh; old_total = old2; new_total = new2;
+        ++k;
+      }
+      // D (k x k, solve order) and W = D^-1
+      D.assign((size_t)k * k, H(0.0));
+      W.assign((size_t)k * k, H(0.0));
+      for (int i = 0; i < k; ++i) {
+        const int64_t ri = row_at(s + i);
+        D[(size_t)i * k + i] = diag[(size_t)ri];
+        for (int64_t e = indptr[ri]; e < indptr[ri + 1]; ++e) {
+          const int32_t j = indices[e];
+          if (j != ri && member[(size_t)j] == nb) D[(size_t)i * k + local[(size_t)j]] = D[(size_t)i * k + local[(size_t)j]] + to_h(values[e]);
+        }
+      }
+      for (int c = 0; c < k; ++c)                              // column c of the inverse by forward substitution
+        for (int i = c; i < k; ++i) {
+          H v = (i == c) ? H(1.0) : H(0.0);
+          for (int l = c; l < i; ++l) v -= D[(size_t)i * k + l] * W[(size_t)l * k + c];
+          W[(size_t)i * k + c] = v / D[(size_t)i * k + i];
+        }
+      // rows of W (D^-1) times the off-block parts
+      for (int i = 0; i < k; ++i) {
+        const int64_t ri = row_at(s + i);
+        touched.clear();
+        for (int l = 0; l <= i; ++l) {
+          const H w = W[(size_t)i * k + l];
+          if (w == H(0.0)) continue;
+          const int64_t rl = row_at(s + l);
+          for (int64_t e = indptr[rl]; e < indptr[rl + 1]; ++e) {
+            const int32_t j = indices[e];
+            if (j == rl || member[(size_t)j] == nb) continue;
+            if (seen[(size_t)j] != -2 - ri) { seen[(size_t)j] = -2 - ri; wv[(size_t)j] = H(0.0); touched.push_back(j); }
+            wv[(size_t)j] += w * to_h(values[e]);
+          }
+        }
+        row_start[(size_t)ri] = (int64_t)pc.size();
+        for (int32_t j : touched) {
+          T v;
+          from_h(wv[(size_t)j], v);
+          pc.push_back(j); pv.push_back(v);
+        }
+        nx[(size_t)ri] = (int32_t)touched.size();
+        for (int l = 0; l <= i; ++l) {
+          const H w = W[(size_t)i * k + l];
+          if (w == H(0.0) && l != i) continue;
+          T v;
+          from_h(-w, v);
+          pc.push_back((int32_t)row_at(s + l)); pv.push_back(v);
+        }
+        row_len[(size_t)ri] = (int64_t)pc.size() - row_start[(size_t)ri];
+        // (the marks of this row must not be mistaken for the chain's: re-mark what the chain has seen)
+        for (int32_t j : touched) seen[(size_t)j] = nb;
+      }
+      s += k;
+      ++nb;
+    }
+    t->nblocks = nb;
+    for (int64_t i = 0; i < n; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + row_len[(size_t)i];
+    cols.resize(pc.size());
+    vals.resize(pv.size());
     for (int64_t i = 0; i < n; ++i) {
-      int32_t l = 0;
-      for (int64_t e = rp[i]; e < rp[i + 1]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
-      level[(size_t)i] = l;
-      nlev = std::max(nlev, l + 1);
+      std::copy(pc.begin() + row_start[(size_t)i], pc.begin() + row_start[(size_t)i] + row_len[(size_t)i], cols.begin() + rp[(size_t)i]);
+      std::copy(pv.begin() + row_start[(size_t)i], pv.begin() + row_start[(size_t)i] + row_len[(size_t)i], vals.begin() + rp[(size_t)i]);
     }
-  } else {
-    for (int64_t i = n - 1; i >= 0; --i) {
-      int32_t l = 0;
-      for (int64_t e = rp[i]; e < rp[i + 1]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
-      level[(size_t)i] = l;
-      nlev = std::max(nlev, l + 1);
-    }
+  }
+  // ---- dependency levels of the transformed rows (x entries only)
+  std::vector<int32_t> level((size_t)n, 0);
+  int32_t nlev = 0;
+  for (int64_t s = 0; s < n; ++s) {
+    const int64_t i = row_at(s);
+    int32_t l = 0;
+    for (int64_t e = rp[(size_t)i]; e < rp[(size_t)i] + nx[(size_t)i]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
+    level[(size_t)i] = l;
+    nlev = std::max(nlev, l + 1);
   }
   t->lev_off.assign((size_t)nlev + 1, 0);
   for (int64_t i = 0; i < n; ++i) t->lev_off[(size_t)level[(size_t)i] + 1]++;
@@ -594,39 +984,48 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     std::vector<int64_t> next(t->lev_off.begin(), t->lev_off.end() - 1);
     for (int64_t i = 0; i < n; ++i) order[(size_t)next[(size_t)level[(size_t)i]]++] = (int32_t)i;   // ascending rows inside a level
   }
-  t->nnz = (int64_t)cols.size();
+  std::vector<int32_t> pos_of((size_t)n);
+  for (int64_t p = 0; p < n; ++p) pos_of[(size_t)order[(size_t)p]] = (int32_t)p;
   {
-    // re-store the entries (and the inverse diagonal) in level order: the rows of a level are then one
-    // contiguous range of positions, their entries one contiguous run
+    // re-store the entries in level order -- the rows of a level are then one contiguous range of positions, their
+    // entries one contiguous run -- every row's x entries sorted by the position of the row they read (oldest
+    // dependency first), its rhs entries behind them
     std::vector<int64_t> rp2((size_t)n + 1, 0);
     std::vector<int32_t> cols2(cols.size());
-    std::vector<T> vals2(vals.size()), dinv2(dinv.size());
+    std::vector<T> vals2(vals.size());
+    t->dep_pos_h.assign(cols.size(), -1);
+    t->nx_h.resize((size_t)n);
+    std::vector<std::pair<int32_t, int64_t>> key;
     int64_t w = 0;
     for (int64_t p = 0; p < n; ++p) {
       const int64_t r = order[(size_t)p];
-      for (int64_t e = rp[(size_t)r]; e < rp[(size_t)r + 1]; ++e, ++w) { cols2[(size_t)w] = cols[(size_t)e]; vals2[(size_t)w] = vals[(size_t)e]; }
+      const int64_t e0 = rp[(size_t)r], ex = e0 + nx[(size_t)r], e1 = rp[(size_t)r + 1];
+      key.clear();
+      for (int64_t e = e0; e < ex; ++e) key.push_back({pos_of[(size_t)cols[(size_t)e]], e});
+      std::sort(key.begin(), key.end());
+      for (auto &ke : key) {
+        cols2[(size_t)w] = cols[(size_t)ke.second];
+        vals2[(size_t)w] = vals[(size_t)ke.second];
+        t->dep_pos_h[(size_t)w] = ke.first;
+        ++w;
+      }
+      for (int64_t e = ex; e < e1; ++e, ++w) { cols2[(size_t)w] = cols[(size_t)e]; vals2[(size_t)w] = vals[(size_t)e]; }
       rp2[(size_t)p + 1] = w;
-      if (!t->unit) dinv2[(size_t)p] = dinv[(size_t)r];
+      t->nx_h[(size_t)p] = nx[(size_t)r];
     }
-    rp.swap(rp2); cols.swap(cols2); vals.swap(vals2); dinv.swap(dinv2);
+    rp.swap(rp2); cols.swap(cols2); vals.swap(vals2);
   }
-  RLH_HIP(hipMalloc((void **)&t->rowptr, (size_t)(n + 1) * sizeof(int64_t)));
-  RLH_HIP(hipMemcpy(t->rowptr, rp.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  t->rowptr_h = rp;
+  t->entries = (int64_t)cols.size();
   RLH_HIP(hipMalloc((void **)&t->cols, std::max<size_t>(cols.size(), 1) * sizeof(int32_t)));
   RLH_HIP(hipMalloc((void **)&t->vals, std::max<size_t>(vals.size(), 1) * sizeof(T)));
   if (!cols.empty()) {
     RLH_HIP(hipMemcpy(t->cols, cols.data(), cols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RLH_HIP(hipMemcpy(t->vals, vals.data(), vals.size() * sizeof(T), hipMemcpyHostToDevice));
   }
-  if (!t->unit) {
-    RLH_HIP(hipMalloc((void **)&t->dinv, (size_t)n * sizeof(T)));
-    RLH_HIP(hipMemcpy(t->dinv, dinv.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice));
-  }
-  RLH_HIP(hipMalloc((void **)&t->lev_off_d, t->lev_off.size() * sizeof(int64_t)));
-  RLH_HIP(hipMemcpy(t->lev_off_d, t->lev_off.data(), t->lev_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   RLH_HIP(hipMalloc((void **)&t->lev_rows, std::max<size_t>((size_t)n, 1) * sizeof(int32_t)));
   if (n > 0) RLH_HIP(hipMemcpy(t->lev_rows, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-  t->device_bytes = (n + 1) * 8 + (int64_t)cols.size() * (4 + (int64_t)sizeof(T)) + n * 4 + (t->unit ? 0 : n * (int64_t)sizeof(T));
+  t->device_bytes = (int64_t)cols.size() * (4 + (int64_t)sizeof(T)) + n * 4 + n * 16;
   return 0;
 }
 
@@ -690,8 +1089,8 @@ int rlh_sptrsv_create(rlh_sptrsv_t *out, int dtype, int64_t n, const int64_t *in
   RLH_REQUIRE(indptr[n] == 0 || (indices && values), "rlh_sptrsv_create: null indices/values");
   rlh_sptrsv *t = new rlh_sptrsv();
   t->dtype = dtype; t->n = n; t->nnz = 0; t->lower = lower ? 1 : 0; t->unit = unit_diag ? 1 : 0;
-  t->rowptr = nullptr; t->cols = nullptr; t->vals = nullptr; t->dinv = nullptr; t->lev_rows = nullptr; t->lev_off_d = nullptr;
-  t->device_bytes = 0; t->work = nullptr; t->work_bytes = 0; t->graph = nullptr; t->graph_key = 0;
+  t->cols = nullptr; t->vals = nullptr; t->lev_rows = nullptr; t->plan_lru = 0; t->entries = 0; t->nblocks = 0;
+  t->device_bytes = 0; t->work = nullptr; t->work_bytes = 0;
   int rc = 1;
   switch (dtype) {
     case RLH_S: rc = sptrsv_build<RLH_S>(t, indptr, indices, values); break;
@@ -735,13 +1134,11 @@ int rlh_sptrsv_destroy(rlh_sptrsv_t t) {
   if (!t) return 0;
   if (ctx().ready) {
     (void)hipStreamSynchronize(ctx().stream);
-    if (t->graph) (void)hipGraphExecDestroy(t->graph);
-    if (t->rowptr) (void)hipFree(t->rowptr);
+    free_plan(&t->plan[0]);
+    free_plan(&t->plan[1]);
     if (t->cols) (void)hipFree(t->cols);
     if (t->vals) (void)hipFree(t->vals);
-    if (t->dinv) (void)hipFree(t->dinv);
     if (t->lev_rows) (void)hipFree(t->lev_rows);
-    if (t->lev_off_d) (void)hipFree(t->lev_off_d);
     if (t->work) (void)hipFree(t->work);
   }
   delete t;
