@@ -1,11 +1,11 @@
-"""Host-side operators adjacent to the hot path.
+"""Operators adjacent to the hot path whose FACTORISATION runs on the host.
 
-The reference's shift-invert operator (PARDISO, raleigh/algebra/sparse_mkl.py:51-119)
-and ILUT preconditioner (sparse_mkl.py:122-140) are MKL host factorisations.  Their
-device counterparts are "next" rows of the scope table; until they land, these
-wrappers run SciPy's SuperLU / ILU on the HOST and move the n x m block across PCIe
-twice per application.  They are NOT part of the hot path and never stand in for a
-HIP kernel: every Vectors operation still runs in librlhip.so.
+The reference's shift-invert operator is PARDISO on the host (raleigh/algebra/sparse_mkl.py:51-119).
+Here SuperLU factorises A - sigma B once on the host; every solve then runs on the device
+(`TriangularChain`: the factors and SuperLU's permutations, one persistent launch on the whole
+n x m block in HBM), so a solver iteration moves no block across PCIe.  `HostOperator` adapts a
+caller's own host operator (two block transfers per application: the caller's choice, never a
+stand-in for a HIP kernel -- every Vectors operation still runs in librlhip.so).
 """
 
 import numpy as np
@@ -31,20 +31,9 @@ class HostOperator:
         y.fill(yh)
 
 
-class IncompleteLU:
-    """Host ILU preconditioner (counterpart of sparse_mkl.py:122-140; SciPy spilu
-    instead of MKL dcsrilut, so iteration counts may differ from the reference's)."""
-
-    def __init__(self, matrix):
-        self._a = scs.csc_matrix(matrix)
-        self._ilu = None
-
-    def factorize(self, tol=1e-6, max_fill=1):
-        self._ilu = sla.spilu(self._a, drop_tol=tol, fill_factor=max(1.0, float(max_fill)) * 10)
-
-    def apply(self, x, y):
-        xh = x.data()
-        y.fill(np.ascontiguousarray(self._ilu.solve(xh.T).T))
+def _lib_error():
+    from ... import _lib
+    return _lib.RlhError
 
 
 class SparseSymmetricSolver:
@@ -82,22 +71,38 @@ class SparseSymmetricSolver:
             raise RuntimeError('factorization failed (near singular matrix?)')
         self._chain = None
 
-    def _device_chain(self):
+    def _device_chain(self, dtype=None):
         """P_r A P_c = L U  =>  x = P_c U^-1 L^-1 P_r b: the scratch row r is row argsort(perm_r)[r] of b,
-        and goes to row argsort(perm_c)[r] of x."""
+        and goes to row argsort(perm_c)[r] of x.  One chain per block data type (the factorisation may be wider
+        than the blocks: analyse() promotes when sigma is a Python float on float32 data)."""
+        dtype = np.dtype(self._dtype if dtype is None else dtype).type
         if self._chain is None:
+            self._chain = {}
+        if dtype not in self._chain:
             from .precond import TriangularChain
             lu = self._lu
             lower = scs.tril(scs.csr_matrix(lu.L), -1, format='csr')        # SuperLU stores the unit diagonal
             upper = scs.csr_matrix(lu.U)
-            self._chain = TriangularChain([(lower, True, True), (upper, False, False)], self._dtype,
-                                          np.argsort(lu.perm_r), np.argsort(lu.perm_c))
-        return self._chain
+            if np.dtype(dtype).kind != 'c' and np.iscomplexobj(upper.data):
+                raise ValueError('complex factors cannot be applied to real vectors')
+            self._chain[dtype] = TriangularChain([(lower, True, True), (upper, False, False)], dtype,
+                                                 np.argsort(lu.perm_r), np.argsort(lu.perm_c))
+        return self._chain[dtype]
 
     def solve(self, b, x):
         if self._device and not hasattr(b, 'comm'):
-            self._device_chain().solve(b, x)
-            return
+            try:
+                chain = self._device_chain(b.data_type())
+            except _lib_error() as e:
+                if 'memory' not in str(e).lower():
+                    raise                       # (a missing library or GPU is an error, never a reason to solve on the host)
+                # factors that do not fit next to the blocks in HBM: the host solve below, loudly
+                import warnings
+                warnings.warn('triangular factors could not be placed on the device (%s): solving on the host' % e)
+                self._device = False
+            else:
+                chain.solve(b, x)
+                return
         bh = b.data()
         x.fill(np.ascontiguousarray(self._lu.solve(np.ascontiguousarray(bh.T)).T, dtype=bh.dtype))
 

@@ -1,8 +1,10 @@
-"""Device-resident polynomial preconditioner.
+"""Device-resident preconditioners.
 
 The reference's preconditioner is MKL's ILUT applied on the host with two triangular solves
-per vector (raleigh/algebra/mkl_wrap.py:279-347); a device counterpart of the same
-factorisation is future work.  This class offers what the survey lists as the alternative: a
+per vector (raleigh/algebra/mkl_wrap.py:279-347).  `IncompleteLU` is its device counterpart:
+the same dual-threshold factorisation on the host once, the triangular solves on the whole
+block in HBM (`TriangularChain`: one persistent launch per application).  `ChebyshevPreconditioner`
+is what the survey lists as the alternative: a
 fixed polynomial p(A) ~ A^-1 (Chebyshev semi-iteration on [lo, hi]) built only from the
 operator's ``apply`` and the block operations, so every block stays in HBM.  p(A) is
 symmetric positive definite for a positive definite A (0 < 1 - r(x) on (0, hi], r the
@@ -20,7 +22,7 @@ from ... import _lib
 
 class TriangularChain:
     """X = T_k^-1 ... T_1^-1 B on the device for sparse triangular factors given as SciPy matrices
-    (level-scheduled solves on the whole n x m block: rlh_sptrsv_create / rlh_sptrsv_solve_chain).
+    (one persistent launch over the whole n x m block: rlh_sptrsv_create / rlh_sptrsv_solve_chain).
 
     factors: list of (matrix, lower, unit_diag); a unit-diagonal factor must not store its diagonal.
     perm_in / perm_out: optional row permutations (row r of the internal block is row perm_in[r] of
@@ -268,73 +270,3 @@ class ChebyshevPreconditioner:
             rho = rho_new
         ua.unpack(y)
         self._work16 = [b, ua, ub]
-
-
-class JacobiSweepILU:
-    """Incomplete factorisation preconditioner applied on the device (the counterpart
-    of the reference's ILUT apply, raleigh/algebra/sparse_mkl.py:122-140 -> mkl_wrap.py:279-347,
-    which runs two triangular solves per vector on the host).
-
-    The factors come from SciPy's ``spilu`` on the host, once (natural ordering, no pivoting); L
-    and the pivots D are kept, i.e. an incomplete L D L^H of the symmetric / Hermitian matrix.
-    The two triangular solves are replaced by `sweeps` Jacobi iterations each,
-        u <- c - L_s u        and        v <- D^-1 u - L_s^H v        (L_s: strictly lower part of L),
-    every sweep one fused pass of the library's sparse kernel over the whole n x m block
-    (`cheb_step_ptr` with (cy, cp, cb) = (0, 0, 1): p = b - A y).  The operator applied is
-    p(L_s)^H D^-1 p(L_s) with p(t) = 1 - t + t^2 - ... (degree `sweeps`): Hermitian positive
-    definite for positive pivots, as the solver requires (raleigh/interfaces/partial_hevp.py:41-49),
-    and equal to the exact (L D L^H)^-1 after n sweeps.  K sweeps only see K dependency levels of
-    the factor, so for long chains (a 3-D stencil in natural order) it is a weak preconditioner;
-    iteration counts are its own."""
-
-    def __init__(self, matrix, sweeps=4, drop_tol=1e-4, fill_factor=10.0):
-        import scipy.sparse as scs
-        import scipy.sparse.linalg as sla
-        from .sparse import CsrOperator
-        a = scs.csc_matrix(matrix)
-        n = a.shape[0]
-        ilu = sla.spilu(a, drop_tol=drop_tol, fill_factor=fill_factor, permc_spec='NATURAL', diag_pivot_thresh=0.0)
-        if not (np.array_equal(ilu.perm_r, np.arange(n)) and np.array_equal(ilu.perm_c, np.arange(n))):
-            raise ValueError('the incomplete factorisation pivoted; JacobiSweepILU needs the natural order')
-        L, U = scs.csr_matrix(ilu.L), scs.csr_matrix(ilu.U)
-        d = U.diagonal()
-        if np.any(d == 0):
-            raise ValueError('zero pivot in the incomplete factorisation')
-        if np.any(d.real <= 0) or np.any(d.imag != 0):
-            raise ValueError('JacobiSweepILU needs positive pivots (a positive definite matrix)')
-        dinv = scs.diags(1.0 / d)
-        self._dtype = a.dtype.type
-        ls = scs.csr_matrix(scs.tril(L, -1), dtype=self._dtype)
-        self._ls = CsrOperator(ls)
-        # the matrix is symmetric / Hermitian, so U = D L^H up to what the dropping rule broke:
-        # D^-1 U_s is taken as L_s^H, which makes the applied operator p(L_s^H) D^-1 p(L_s) exactly
-        # Hermitian positive definite (SciPy's dropping is not symmetric, and the solver's
-        # convergence tests assume a symmetric preconditioner)
-        self._ut = CsrOperator(scs.csr_matrix(ls.conj().T, dtype=self._dtype))
-        self._dinv = CsrOperator(scs.csr_matrix(dinv, dtype=self._dtype))
-        self._sweeps = int(sweeps)
-        self._work = None
-        self.fill = (L.nnz + U.nnz - n) / float(a.nnz)
-
-    def _sweep(self, op, c, start, a, b):
-        """z_K of z_{k+1} = c - op z_k, z_0 = start; a, b: work blocks (start and c are only read)."""
-        m = c.nvec()
-        z, out = start, a
-        for _ in range(self._sweeps):
-            op.cheb_step_ptr(m, z, out, c, 0.0, 0.0, 1.0)            # out = c - op z  (0 * old out: finite)
-            z, out = out, (b if out is a else a)
-        return z
-
-    def apply(self, x, y):
-        m = x.nvec()
-        if self._work is None or self._work[0].shape()[0] < m or self._work[0].dimension() != x.dimension():
-            self._work = [x.new_vectors(m) for _ in range(3)]
-            for w in self._work:
-                w.zero()                             # the fused step multiplies the old contents by 0
-        for w in self._work:
-            w.select(m)
-        w0, w1, w2 = self._work
-        u = self._sweep(self._ls, x, x, w0, w1)                      # u ~ L^-1 x
-        self._dinv.apply_ptr(m, u.data_ptr(), u.ld(), w2.data_ptr(), w2.ld())    # t = D^-1 u
-        v = self._sweep(self._ut, w2, w2, w0, w1)                    # v ~ (D^-1 U)^-1 t
-        v.copy(y)

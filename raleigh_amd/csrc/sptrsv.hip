@@ -30,7 +30,7 @@ struct rlh_factors {
 };
 
 namespace rlh { struct TrsvUnit; struct TrsvRow; }
-struct TrsvPlan {                  // units and far / near split of an operator for `pl` lanes across the pieces of a row
+struct TrsvPlan {                  // units of an operator for `pl` lanes across the pieces of a row
   int pl = 0;
   int64_t nunits = 0;
   rlh::TrsvUnit *units = nullptr;  // device
@@ -41,17 +41,20 @@ struct rlh_sptrsv {
   int dtype;
   int64_t n, nnz;                  // nnz: stored off-diagonal entries
   int lower, unit;
-  // device arrays in LEVEL order: position p holds row lev_rows[p]; its off-diagonal entries are one
-  // contiguous run of cols / vals: x entries (column = ORIGINAL row number; sorted by the position of that row, so
-  // the oldest dependencies come first), then rhs entries (see sptrsv_build)
+  // device arrays in LEVEL order: position p holds one row (pos_of maps rows to positions); its entries are one
+  // contiguous run of cols / vals: x entries (column = the POSITION of the row read, ascending: the oldest dependencies
+  // come first), then rhs entries (column = original row; see sptrsv_build).  The result image of an operator is
+  // indexed by position too: rows of one level that read neighbouring rows of an earlier level -- any structured grid
+  // or node-blocked matrix -- then gather neighbouring pieces, which the memory pipeline merges into few requests
   int32_t *cols;
   void *vals;
-  int32_t *lev_rows;               // the rows ordered by level
+  int32_t *pos_of;                 // row -> position
   std::vector<int64_t> lev_off;    // host: first position of every level, nlevels + 1
   std::vector<int64_t> rowptr_h;   // host: first entry of every position, n + 1
   std::vector<int32_t> dep_pos_h;  // host: per x entry, the position of the row it reads (plans are built from it)
   std::vector<int32_t> nx_h;       // host: x entries of every position (its rhs entries follow them)
   int64_t entries, nblocks;        // stored entries after the block transform; diagonal blocks
+  int64_t levels_plain;            // dependency levels of the factor as given
   TrsvPlan plan[2];
   int plan_lru;
   int64_t device_bytes;
@@ -174,15 +177,16 @@ static int ilut_factor(int64_t n, const int64_t *indptr, const int32_t *indices,
 //    (every 32-bit word 0xFFFFDEAD), a consumer re-reads a piece until none of its 8-byte halves
 //    carries that pattern, a producer never stores it (a result that happens to be this NaN is
 //    rewritten as the canonical quiet NaN).  A piece is written once, by one lane, in one store.
-//  * Queue.  The rows are cut into UNITS of at most 256 (row, lane) tasks inside one level, listed
-//    in level order; workgroups take units from one counter per group.  A unit only ever waits for
-//    units taken earlier, which are held by resident workgroups: no placement or residency
-//    assumption, no grid barrier.
-//  * Throttle.  Polling every referenced piece from the moment a unit is taken would swamp the L2, so
-//    a unit records the last unit its FAR entries (dependencies at least kNearWindow units back) and
-//    its NEAR entries need, every unit raises a done word when its stores have left, and one lane
-//    sleeps on those two words -- first coarsely on a word 32 units earlier -- before the workgroup
-//    gathers.  The words are hints (a stale one costs polls, not correctness).
+//  * Queue.  The rows are cut into UNITS of at most 256 (row, lane) tasks inside one level -- enough lanes per row
+//    that a lane holds at most four entries: ONE batch, whose indices and values are in registers before the first
+//    poll -- listed in level order; workgroups take units from one counter per group (the next unit's number is
+//    fetched while the current one is worked on).  A unit only ever waits for units taken earlier, which are held
+//    by resident workgroups: no placement or residency assumption, no grid barrier, no deadlock.
+//  * Polls.  A lane asks again only for the pieces it is still missing (every 16-byte gather is an L2 request of
+//    its own and a CU issues one per clock), with an s_sleep between rounds.  Measured on the box
+//    (profiles/r03_trsv_*.txt): gating the polls behind per-unit done words -- so that only the units next to the
+//    front poll -- was slower at every window size than letting every resident unit poll from the moment it is
+//    taken; what pays is the NUMBER of units in flight, so the kernel is kept small in registers.
 //  * Every spin is bounded (wall clock, and an error word another workgroup may have raised): a
 //    protocol failure ends the launch with NaNs in the result and rlh_sync / the next call report it.
 
@@ -202,32 +206,29 @@ template <> struct Halves64<c64> { static constexpr bool value = true; };
 
 
 constexpr unsigned kSentinel = 0xFFFFDEADu;     // as a float, and as the high word of a double: a NaN
-constexpr int kNearWindow = 12;                 // units: dependencies closer than this are gathered last
-constexpr int kCoarse = 32;                     // units between the coarse and the fine done word of a wait
 constexpr int kMaxXcd = 8;
 constexpr int kCtrlHead = 32;                   // words: [0] next group, [1] error, [2] census
 constexpr unsigned long long kSpinTicks = 400000000ull;      // 4 s of the 100 MHz wall clock
 
-struct alignas(16) TrsvUnit {
+struct alignas(16) TrsvUnit {                    // 16 bytes
   int32_t p0; uint16_t nr; uint8_t lg_lr, pad;
-  int32_t far_unit;             // the last unit a far entry reads (-1: none)
   int32_t near_unit;            // the last unit any x entry reads (-1: none)
-  int32_t thr_unit;             // far entries read units <= thr_unit; the near ones are polled for once it is done (-1: at once)
-  int32_t pad2[3];
+  int32_t pad2;
 };
-struct alignas(16) TrsvRow { int64_t e0; int32_t nfar; uint16_t nnear, nrhs; };   // x entries far | near, then rhs entries
+struct alignas(16) TrsvRow { int64_t e0; int32_t nx, nrhs; };   // x entries, then rhs entries
 
 struct TrsvOp {
   const TrsvUnit *units;
   const TrsvRow *rows;
-  const int32_t *lev_rows, *cols;
+  const int32_t *cols;
+  const int32_t *prev_pos;                      // row -> position in the image this operator's rhs entries read (null: identity)
   const void *vals;
   int32_t unit0, nunits;
 };
 
 struct TrsvArgs {
   TrsvOp op[8];
-  int nops, total_units, ngroups, ppt, pl, done_stride, tune;
+  int nops, total_units, ngroups, ppt, pl;
   int64_t n8;
   u32x4 *scratch;
   unsigned *ctrl;
@@ -296,19 +297,6 @@ struct Watch {                                  // bounds every spin of one thre
   }
 };
 
-__device__ __forceinline__ void wait_word(const unsigned *w, int sleep, Watch &watch) {
-  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-    if (sleep > 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(1);
-    if (watch.expired()) break;
-  }
-}
-// one lane: sleep until unit k of this group (a hint) is done -- coarsely on an earlier unit's word first
-__device__ __forceinline__ void wait_unit(const unsigned *done, int k, Watch &watch) {
-  if (k < 0) return;
-  if (k >= kCoarse) wait_word(done + (k - kCoarse), 32, watch);
-  wait_word(done + k, 1, watch);
-}
-
 // which group does XCD `xcc` solve in its round `round`?  The first of its workgroups to ask takes the next
 // unclaimed group for the XCD; -1: none left.
 __device__ __forceinline__ int claim_group(unsigned *ctrl, unsigned xcc, int round, int ngroups, Watch &watch) {
@@ -335,10 +323,11 @@ __device__ __forceinline__ int claim_group(unsigned *ctrl, unsigned xcc, int rou
 template <typename T> struct Batch { int32_t c[4]; T v[4]; unsigned rhs; };
 
 // entries e, e + sl, e + 2 sl, e + 3 sl of a row (those beyond `end` repeat the first with value 0); bit u of `rhs`:
-// entry u lies at or beyond end_x, i.e. it reads the right-hand side image, not the result image
+// entry u lies at or beyond end_x, i.e. it reads the right-hand side image (where the previous operator keeps that row:
+// prev_pos), not the result image
 template <typename T>
 __device__ __forceinline__ Batch<T> load_batch(const int32_t *__restrict__ cols, const T *__restrict__ vals, int64_t e, int64_t end, int sl,
-                                               int64_t end_x) {
+                                               int64_t end_x, const int32_t *__restrict__ prev_pos) {
   Batch<T> b;
   b.rhs = 0u;
 #pragma unroll
@@ -350,41 +339,48 @@ __device__ __forceinline__ Batch<T> load_batch(const int32_t *__restrict__ cols,
     b.v[u] = in ? neg_of(vals[ec]) : zero_of(T{});
     if (ec >= end_x) b.rhs |= 1u << u;
   }
+  if (prev_pos && b.rhs) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (b.rhs & (1u << u)) b.c[u] = prev_pos[b.c[u]];
+  }
   return b;
 }
 
-// up to four L1-bypassing loads in flight, one wait: only the first `cnt` are issued (every load is an L2 request of
-// its own -- a workgroup's gathers queue at its CU's one request per clock -- so padding slots must not load)
-__device__ __forceinline__ void loadn_sc1(int cnt, const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, u32x4 &x0,
+// L1-bypassing loads of those of four pieces whose bit is set in `want`, one wait (every load is an L2 request of its
+// own -- a workgroup's gathers queue at its CU's one request per clock -- so neither padding slots nor pieces that
+// have arrived are asked for again)
+__device__ __forceinline__ void loadm_sc1(unsigned want, const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, u32x4 &x0,
                                           u32x4 &x1, u32x4 &x2, u32x4 &x3) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x0) : "v"(p0) : "memory");
-  if (cnt > 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x1) : "v"(p1) : "memory");
-  if (cnt > 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x2) : "v"(p2) : "memory");
-  if (cnt > 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x3) : "v"(p3) : "memory");
+  if (want & 1u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x0) : "v"(p0) : "memory");
+  if (want & 2u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x1) : "v"(p1) : "memory");
+  if (want & 4u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x2) : "v"(p2) : "memory");
+  if (want & 8u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x3) : "v"(p3) : "memory");
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "memory");
 }
 
 // acc -= sum over this lane's entries [e, end) (stride sl) of value * (X or, from end_x on, R)[column]; `cur` holds the
-// first batch
+// first batch.  A piece that has not arrived is asked for again (and only it) until it has.
 template <typename T>
 __device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T> cur, int64_t e, int64_t end, int64_t end_x, int sl,
                                            const int32_t *__restrict__ cols, const T *__restrict__ vals, const u32x4 *X, const u32x4 *R,
-                                           int ppt, int pp, int tune, Watch &watch) {
+                                           const int32_t *__restrict__ prev_pos, int ppt, int pp, Watch &watch) {
   constexpr int EPL = PieceOf<T>::EPL;
   while (e < end) {
     const int64_t en = e + 4 * (int64_t)sl;
-    Batch<T> next = cur;
-    if (en < end) next = load_batch<T>(cols, vals, en, end, sl, end_x);
     const int cnt = en <= end ? 4 : (int)((end - e + sl - 1) / sl);
     const u32x4 *p0 = ((cur.rhs & 1u) ? R : X) + (int64_t)cur.c[0] * ppt + pp, *p1 = ((cur.rhs & 2u) ? R : X) + (int64_t)cur.c[1] * ppt + pp;
     const u32x4 *p2 = ((cur.rhs & 4u) ? R : X) + (int64_t)cur.c[2] * ppt + pp, *p3 = ((cur.rhs & 8u) ? R : X) + (int64_t)cur.c[3] * ppt + pp;
     typename PieceOf<T>::U x0, x1, x2, x3;
-    loadn_sc1(cnt, p0, p1, p2, p3, x0.w, x1.w, x2.w, x3.w);
-    while (!(piece_ready<T>(x0.w) && (cnt < 2 || piece_ready<T>(x1.w)) && (cnt < 3 || piece_ready<T>(x2.w)) &&
-             (cnt < 4 || piece_ready<T>(x3.w)))) {
-      if (!(tune & 2)) __builtin_amdgcn_s_sleep(1);
-      if (watch.expired()) break;
-      loadn_sc1(cnt, p0, p1, p2, p3, x0.w, x1.w, x2.w, x3.w);
+    unsigned want = (1u << cnt) - 1u;
+    for (;;) {
+      loadm_sc1(want, p0, p1, p2, p3, x0.w, x1.w, x2.w, x3.w);
+      if ((want & 1u) && piece_ready<T>(x0.w)) want &= ~1u;
+      if ((want & 2u) && piece_ready<T>(x1.w)) want &= ~2u;
+      if ((want & 4u) && piece_ready<T>(x2.w)) want &= ~4u;
+      if ((want & 8u) && piece_ready<T>(x3.w)) want &= ~8u;
+      if (want == 0u || watch.expired()) break;
+      __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
@@ -393,8 +389,8 @@ __device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T>
       if (cnt > 2) fma_acc(acc.e[q], cur.v[2], x2.e[q]);
       if (cnt > 3) fma_acc(acc.e[q], cur.v[3], x3.e[q]);
     }
-    cur = next;
     e = en;
+    if (e < end) cur = load_batch<T>(cols, vals, e, end, sl, end_x, prev_pos);
   }
 }
 
@@ -424,7 +420,6 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
   Watch watch{a.ctrl, a.err_host, (unsigned long long)wall_clock64(), 0u, false};
   const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & (kMaxXcd - 1);   // HW_REG_XCC_ID
   unsigned *const queues = a.ctrl + kCtrlHead + kMaxXcd * (a.ngroups + 1);
-  unsigned *const flags = queues + 32 * a.ngroups;
   for (int round = 0; round <= a.ngroups; ++round) {
     if (tid == 0) s_pick[0] = claim_group(a.ctrl, xcc, round, a.ngroups, watch);
     __syncthreads();
@@ -432,7 +427,6 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
     __syncthreads();
     if (g < 0) break;
     unsigned *const qhead = queues + 32 * g;
-    unsigned *const done = flags + (int64_t)g * a.done_stride;
     if (tid == 0) s_pick[0] = (int)__hip_atomic_fetch_add(qhead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     for (int it = 0;; ++it) {
@@ -456,14 +450,12 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
       const bool live = row_slot < (int)ud.nr;
       const int64_t p = ud.p0 + (live ? row_slot : 0);
       const TrsvRow rd = o.rows[p];
-      const int64_t r = o.lev_rows[p];
       const int32_t *__restrict__ cols = o.cols;
       const T *__restrict__ vals = (const T *)o.vals;
       const int ppt = a.ppt;
       const u32x4 *rhs = a.scratch + ((int64_t)k * a.ngroups + g) * a.n8 * ppt;
       u32x4 *X = a.scratch + ((int64_t)(k + 1) * a.ngroups + g) * a.n8 * ppt;
-      const int64_t e_far = rd.e0 + slice, end_far = rd.e0 + rd.nfar;
-      const int64_t e_near = end_far + slice, end_x = end_far + rd.nnear, end_all = end_x + rd.nrhs;
+      const int64_t e_first = rd.e0 + slice, end_x = rd.e0 + rd.nx, end_all = end_x + rd.nrhs;
       bool first = true;
       for (int pp0 = 0; pp0 < ppt; pp0 += PL) {               // (one trip unless a group holds more than 64 pieces of a row)
         const int pq = pp0 + pl;
@@ -472,39 +464,24 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
         PU acc;
 #pragma unroll
         for (int q = 0; q < EPL; ++q) acc.e[q] = zero_of(T{});
-        Batch<T> bf, bn;
-        if (work && e_far < end_far) bf = load_batch<T>(cols, vals, e_far, end_far, sl, end_far);
-        if (work && e_near < end_all) bn = load_batch<T>(cols, vals, e_near, end_all, sl, end_x);
+        Batch<T> cur;
+        if (work && e_first < end_all) cur = load_batch<T>(cols, vals, e_first, end_all, sl, end_x, o.prev_pos);
         const bool owner = work && slice == 0;
-        if (owner && !(a.tune & 8)) {
+        if (owner) {
           // the line this row's result will be stored into, brought into the L2 now: a consumer's poll of a line the L2
           // holds only the freshly stored bytes of would go to memory for the rest of it
-          const u32x4 warm = load_sc1(X + r * ppt + pp);
+          const u32x4 warm = load_sc1(X + p * ppt + pp);
           asm volatile("" :: "v"(warm));
         }
-        if (first) {                                           // the far entries: dependencies at least kNearWindow units back
-          if (stamp) stamp[1] = wall_clock64();
-          if (tid == 0) wait_unit(done, ud.far_unit < 0 ? -1 : o.unit0 + ud.far_unit, watch);
-          __syncthreads();
-          if (stamp) stamp[2] = wall_clock64();
-        }
-        if (work) accumulate<T>(acc, bf, e_far, end_far, end_far, sl, cols, vals, X, rhs, ppt, pp, a.tune, watch);
-        if (first) {
-          // the near entries are polled piece by piece, which only the units next to the front may do: wait for the unit
-          // kNearWindow back (units finish roughly in order; what is still missing then is polled for)
-          if (stamp) stamp[3] = wall_clock64();
-          if (tid == 0 && ud.near_unit > ud.far_unit && ud.thr_unit >= 0) wait_unit(done, o.unit0 + ud.thr_unit, watch);
-          __syncthreads();
-          if (stamp) stamp[4] = wall_clock64();
-        }
-        if (work) accumulate<T>(acc, bn, e_near, end_all, end_x, sl, cols, vals, X, rhs, ppt, pp, a.tune, watch);
+        if (first && stamp) stamp[4] = wall_clock64();
+        if (work) accumulate<T>(acc, cur, e_first, end_all, end_x, sl, cols, vals, X, rhs, o.prev_pos, ppt, pp, watch);
         if (first && stamp) stamp[5] = wall_clock64();
         first = false;
         // sum of the slices of a row: lanes PL apart inside a wave, then (rows wider than a wave) through the LDS
         {
           const int top = lr < 64 ? lr : 64;
           int off = PL;
-          if (PL == 1 && !(a.tune & 4)) {
+          if (PL == 1) {
             // adjacent lanes: the first four steps are data-parallel-primitive moves inside a row of 16 lanes (no LDS
             // crossbar round trip per step): pairs, quads (quad_perm), the two quads of a half (row_half_mirror),
             // the two halves (row_mirror) -- any pairing of distinct partial sums will do for a sum
@@ -537,15 +514,13 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
           __syncthreads();
         }
         if (stamp && pp0 == 0) stamp[8] = wall_clock64();
-        if (owner) X[r * ppt + pp] = piece_clean<T>(acc.w);
+        if (owner) X[p * ppt + pp] = piece_clean<T>(acc.w);
         if (stamp && pp0 == 0) stamp[9] = wall_clock64();
       }
-      // every wave has ISSUED its stores (the done word is a hint: it need not wait for them to land), and the next
-      // pick is in the LDS
+      // the next pick is in the LDS (the stores need not have landed: nobody is told, consumers poll the pieces)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (stamp) stamp[10] = wall_clock64();
       __builtin_amdgcn_s_barrier();
-      if (tid == 0) *(volatile unsigned *)(done + U) = 1u;
       if (stamp) { stamp[6] = wall_clock64(); stamp[7] = ((unsigned long long)(unsigned)(o.unit0 + ud.near_unit) << 32) | (xcc << 24) | (unsigned)blockIdx.x; }
     }
     __syncthreads();
@@ -584,8 +559,8 @@ __global__ __launch_bounds__(256) void trsv_scatter_in(const T *__restrict__ B, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void trsv_gather_out(const u32x4 *__restrict__ res, const int64_t *__restrict__ perm, T *__restrict__ X,
-                                                       int64_t ldx, int64_t n, int64_t n8, int m, int ngroups, int ppt) {
+__global__ __launch_bounds__(256) void trsv_gather_out(const u32x4 *__restrict__ res, const int32_t *__restrict__ pos, const int64_t *__restrict__ perm,
+                                                       T *__restrict__ X, int64_t ldx, int64_t n, int64_t n8, int m, int ngroups, int ppt) {
   constexpr int EPL = PieceOf<T>::EPL;
   const int64_t total = n * ngroups * ppt;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -594,7 +569,7 @@ __global__ __launch_bounds__(256) void trsv_gather_out(const u32x4 *__restrict__
   const int64_t gq = t / n;
   const int q = (int)(gq % ppt), g = (int)(gq / ppt);
   typename PieceOf<T>::U in;
-  in.w = res[((int64_t)g * n8 + r) * ppt + q];
+  in.w = res[((int64_t)g * n8 + pos[r]) * ppt + q];                // (the last operator keeps row r at its position)
   const int64_t dst = perm ? perm[r] : r;
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
@@ -610,13 +585,12 @@ static int pow2_ceil(int64_t v) {
   return p;
 }
 
-// Units, far / near split and wait words of one operator for PL lanes across the pieces of a row.
+// Units and wait words of one operator for PL lanes across the pieces of a row.
 static int build_plan(rlh_sptrsv *t, int pl, TrsvPlan *plan) {
   const int64_t n = t->n;
   const int64_t nlev = (int64_t)t->lev_off.size() - 1;
   std::vector<TrsvUnit> units;
   std::vector<int32_t> unit_of((size_t)n);
-  std::vector<int32_t> last_unit_of_level((size_t)nlev, -1), level_of_unit;
   for (int64_t lev = 0; lev < nlev; ++lev) {
     const int64_t p0 = t->lev_off[(size_t)lev], p1 = t->lev_off[(size_t)lev + 1];
     const int64_t nrows = p1 - p0;
@@ -638,22 +612,11 @@ static int build_plan(rlh_sptrsv *t, int pl, TrsvPlan *plan) {
       const int64_t cnt = nrows / nu + (u < nrows % nu ? 1 : 0);
       TrsvUnit d;
       memset(&d, 0, sizeof(d));
-      d.p0 = (int32_t)p; d.nr = (uint16_t)cnt; d.lg_lr = (uint8_t)lg; d.far_unit = -1; d.near_unit = -1; d.thr_unit = -1;
-      level_of_unit.push_back((int32_t)lev);
+      d.p0 = (int32_t)p; d.nr = (uint16_t)cnt; d.lg_lr = (uint8_t)lg; d.near_unit = -1;
       for (int64_t q = p; q < p + cnt; ++q) unit_of[(size_t)q] = (int32_t)units.size();
       units.push_back(d);
       p += cnt;
     }
-    last_unit_of_level[(size_t)lev] = (int32_t)units.size() - 1;
-  }
-  // FAR entries of a unit of level L: what lies at least two levels AND kNearWindow units back -- gathered when the
-  // last of those units is done, long before the unit's turn; the rest (the level before, and whatever is close in the
-  // queue) is polled for once that boundary unit is done, by about a level's worth of units at a time
-  for (size_t u = 0; u < units.size(); ++u) {
-    const int32_t lev = level_of_unit[u];
-    int32_t thr = (int32_t)u - kNearWindow;
-    if (lev >= 2) thr = std::min(thr, last_unit_of_level[(size_t)lev - 2]); else thr = -1;
-    units[u].thr_unit = thr < 0 ? -1 : thr;
   }
   RLH_REQUIRE(units.size() < ((size_t)1 << 30), "rlh_sptrsv: too many units");
   std::vector<TrsvRow> rows((size_t)std::max<int64_t>(n, 1));
@@ -661,13 +624,8 @@ static int build_plan(rlh_sptrsv *t, int pl, TrsvPlan *plan) {
     const int64_t e0 = t->rowptr_h[(size_t)p], e1 = t->rowptr_h[(size_t)p + 1], ex = e0 + t->nx_h[(size_t)p];
     const int32_t u = unit_of[(size_t)p];
     TrsvUnit &d = units[(size_t)u];
-    // the x entries of a row are sorted by the position of the row they read: its far entries are a prefix
-    int64_t nfar = 0;
-    while (e0 + nfar < ex && unit_of[(size_t)t->dep_pos_h[(size_t)(e0 + nfar)]] <= d.thr_unit) ++nfar;
-    if (nfar > 0) d.far_unit = std::max(d.far_unit, unit_of[(size_t)t->dep_pos_h[(size_t)(e0 + nfar - 1)]]);
     if (ex > e0) d.near_unit = std::max(d.near_unit, unit_of[(size_t)t->dep_pos_h[(size_t)(ex - 1)]]);
-    RLH_REQUIRE(ex - e0 - nfar < 65536 && e1 - ex < 65536, "rlh_sptrsv: a row has too many near entries");
-    rows[(size_t)p] = TrsvRow{e0, (int32_t)nfar, (uint16_t)(ex - e0 - nfar), (uint16_t)(e1 - ex)};
+    rows[(size_t)p] = TrsvRow{e0, (int32_t)(ex - e0), (int32_t)(e1 - ex)};
   }
   plan->pl = pl;
   plan->nunits = (int64_t)units.size();
@@ -718,14 +676,14 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
   for (int i = 0; i < nops; ++i) {
     TrsvPlan *plan = nullptr;
     if (int rc = plan_for(ops[i], pl, &plan)) return rc;
-    a.op[i].units = plan->units; a.op[i].rows = plan->rows; a.op[i].lev_rows = ops[i]->lev_rows; a.op[i].cols = ops[i]->cols;
+    a.op[i].units = plan->units; a.op[i].rows = plan->rows; a.op[i].cols = ops[i]->cols;
+    a.op[i].prev_pos = i > 0 ? ops[i - 1]->pos_of : nullptr;
     a.op[i].vals = ops[i]->vals;
     a.op[i].unit0 = (int32_t)total_units; a.op[i].nunits = (int32_t)plan->nunits;
     total_units += plan->nunits;
   }
   RLH_REQUIRE(total_units < ((int64_t)1 << 30), "rlh_sptrsv_solve_chain: too many units");
-  const int64_t done_stride = (total_units + 31) & ~(int64_t)31;
-  const int64_t ctrl_words = kCtrlHead + kMaxXcd * (ngroups + 1) + 32 * (int64_t)ngroups + (int64_t)ngroups * done_stride;
+  const int64_t ctrl_words = kCtrlHead + kMaxXcd * (ngroups + 1) + 32 * (int64_t)ngroups;
   const int64_t ctrl_bytes = ((ctrl_words * 4 + 15) / 16) * 16;
   const int64_t slot_pieces = (int64_t)ngroups * n8 * ppt;
   const int64_t scratch_bytes = (int64_t)(nops + 1) * slot_pieces * 16;
@@ -737,12 +695,11 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
     RLH_HIP(hipMalloc(&head->work, (size_t)need));
     head->work_bytes = need;
   }
-  a.nops = nops; a.total_units = (int)total_units; a.ngroups = ngroups; a.ppt = ppt; a.pl = pl; a.done_stride = (int)done_stride;
+  a.nops = nops; a.total_units = (int)total_units; a.ngroups = ngroups; a.ppt = ppt; a.pl = pl;
   a.n8 = n8;
   a.ctrl = (unsigned *)head->work;                            // (the control words open the allocation: zeroed per call)
   a.scratch = (u32x4 *)((char *)head->work + ctrl_bytes);
   a.err_host = c.async_err_d;
-  { const char *e = getenv("RLH_SPTRSV_TUNE"); a.tune = (e && *e) ? atoi(e) : 0; }      // experiments (see tools/trsv_run.sh)
   const char *trace_path = getenv("RLH_SPTRSV_TRACE");      // diagnostics: per-unit stamps of group 0 to this file (synchronises)
   if (trace_path && *trace_path) {
     RLH_HIP(hipMalloc((void **)&a.trace, (size_t)total_units * 128));
@@ -772,7 +729,8 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
   {
     const int64_t nb = (n * ngroups * ppt + 255) / 256;
     hipLaunchKernelGGL((trsv_gather_out<T>), dim3((unsigned)nb), dim3(256), 0, c.stream,
-                       (const u32x4 *)(a.scratch + (int64_t)nops * slot_pieces), perm_out, (T *)X_, ldx, n, n8, (int)m, ngroups, ppt);
+                       (const u32x4 *)(a.scratch + (int64_t)nops * slot_pieces), ops[nops - 1]->pos_of, perm_out, (T *)X_, ldx, n, n8, (int)m,
+                       ngroups, ppt);
     RLH_HIP(hipGetLastError());
   }
   if (a.trace) {
@@ -846,14 +804,18 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
   t->nnz = nstrict;
   auto row_at = [&](int64_t s) -> int64_t { return t->lower ? s : n - 1 - s; };      // solve order
   // ---- the transformed rows: x entries (column, m) then rhs entries (row, -w), per ORIGINAL row
-  std::vector<int64_t> rp((size_t)n + 1, 0);
-  std::vector<int32_t> nx((size_t)n, 0);
+  std::vector<int64_t> rp;
+  std::vector<int32_t> nx;
   std::vector<int32_t> cols;
   std::vector<T> vals;
-  cols.reserve((size_t)nstrict + (size_t)n);
-  vals.reserve((size_t)nstrict + (size_t)n);
-  {
-    const int B = block_limit();
+  std::vector<int32_t> level((size_t)n, 0);
+  int32_t nlev = 0;
+  auto transform = [&](const int B) {
+    rp.assign((size_t)n + 1, 0);
+    nx.assign((size_t)n, 0);
+    cols.clear(); vals.clear();
+    cols.reserve((size_t)nstrict + (size_t)n);
+    vals.reserve((size_t)nstrict + (size_t)n);
     const double fmax = 0.3;
     std::vector<int64_t> seen((size_t)n, -1), member((size_t)n, -1);
     std::vector<int32_t> local((size_t)n, 0);
@@ -965,16 +927,32 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
       std::copy(pc.begin() + row_start[(size_t)i], pc.begin() + row_start[(size_t)i] + row_len[(size_t)i], cols.begin() + rp[(size_t)i]);
       std::copy(pv.begin() + row_start[(size_t)i], pv.begin() + row_start[(size_t)i] + row_len[(size_t)i], vals.begin() + rp[(size_t)i]);
     }
-  }
-  // ---- dependency levels of the transformed rows (x entries only)
-  std::vector<int32_t> level((size_t)n, 0);
-  int32_t nlev = 0;
-  for (int64_t s = 0; s < n; ++s) {
-    const int64_t i = row_at(s);
-    int32_t l = 0;
-    for (int64_t e = rp[(size_t)i]; e < rp[(size_t)i] + nx[(size_t)i]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
-    level[(size_t)i] = l;
-    nlev = std::max(nlev, l + 1);
+    // dependency levels of the transformed rows (x entries only)
+    nlev = 0;
+    for (int64_t s = 0; s < n; ++s) {
+      const int64_t i = row_at(s);
+      int32_t l = 0;
+      for (int64_t e = rp[(size_t)i]; e < rp[(size_t)i] + nx[(size_t)i]; ++e) l = std::max(l, level[(size_t)cols[(size_t)e]] + 1);
+      level[(size_t)i] = l;
+      nlev = std::max(nlev, l + 1);
+    }
+  };
+  // what the transform is for is fewer levels: where it removes less than 30 % of them (a 7-point stencil: its chains
+  // along x are not what makes its factors deep) the extra entries cost more than the levels saved
+  {
+    int32_t plain = 0;
+    for (int64_t s = 0; s < n; ++s) {
+      const int64_t i = row_at(s);
+      int32_t l = 0;
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e)
+        if (indices[e] != i) l = std::max(l, level[(size_t)indices[e]] + 1);
+      level[(size_t)i] = l;
+      plain = std::max(plain, l + 1);
+    }
+    t->levels_plain = plain;
+    const int B = block_limit();
+    transform(B);
+    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.7 * (double)plain) transform(1);
   }
   t->lev_off.assign((size_t)nlev + 1, 0);
   for (int64_t i = 0; i < n; ++i) t->lev_off[(size_t)level[(size_t)i] + 1]++;
@@ -1004,7 +982,7 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
       for (int64_t e = e0; e < ex; ++e) key.push_back({pos_of[(size_t)cols[(size_t)e]], e});
       std::sort(key.begin(), key.end());
       for (auto &ke : key) {
-        cols2[(size_t)w] = cols[(size_t)ke.second];
+        cols2[(size_t)w] = ke.first;
         vals2[(size_t)w] = vals[(size_t)ke.second];
         t->dep_pos_h[(size_t)w] = ke.first;
         ++w;
@@ -1023,8 +1001,8 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     RLH_HIP(hipMemcpy(t->cols, cols.data(), cols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RLH_HIP(hipMemcpy(t->vals, vals.data(), vals.size() * sizeof(T), hipMemcpyHostToDevice));
   }
-  RLH_HIP(hipMalloc((void **)&t->lev_rows, std::max<size_t>((size_t)n, 1) * sizeof(int32_t)));
-  if (n > 0) RLH_HIP(hipMemcpy(t->lev_rows, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  RLH_HIP(hipMalloc((void **)&t->pos_of, std::max<size_t>((size_t)n, 1) * sizeof(int32_t)));
+  if (n > 0) RLH_HIP(hipMemcpy(t->pos_of, pos_of.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
   t->device_bytes = (int64_t)cols.size() * (4 + (int64_t)sizeof(T)) + n * 4 + n * 16;
   return 0;
 }
@@ -1089,7 +1067,7 @@ int rlh_sptrsv_create(rlh_sptrsv_t *out, int dtype, int64_t n, const int64_t *in
   RLH_REQUIRE(indptr[n] == 0 || (indices && values), "rlh_sptrsv_create: null indices/values");
   rlh_sptrsv *t = new rlh_sptrsv();
   t->dtype = dtype; t->n = n; t->nnz = 0; t->lower = lower ? 1 : 0; t->unit = unit_diag ? 1 : 0;
-  t->cols = nullptr; t->vals = nullptr; t->lev_rows = nullptr; t->plan_lru = 0; t->entries = 0; t->nblocks = 0;
+  t->cols = nullptr; t->vals = nullptr; t->pos_of = nullptr; t->plan_lru = 0; t->entries = 0; t->nblocks = 0; t->levels_plain = 0;
   t->device_bytes = 0; t->work = nullptr; t->work_bytes = 0;
   int rc = 1;
   switch (dtype) {
@@ -1138,7 +1116,7 @@ int rlh_sptrsv_destroy(rlh_sptrsv_t t) {
     free_plan(&t->plan[1]);
     if (t->cols) (void)hipFree(t->cols);
     if (t->vals) (void)hipFree(t->vals);
-    if (t->lev_rows) (void)hipFree(t->lev_rows);
+    if (t->pos_of) (void)hipFree(t->pos_of);
     if (t->work) (void)hipFree(t->work);
   }
   delete t;

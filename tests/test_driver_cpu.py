@@ -71,9 +71,9 @@ def test_partial_hevp_shift_invert_config1(golden_dir):
 
 
 def test_partial_hevp_ilu_config3_mode(golden_dir):
-    """Preconditioned mode of config 3 on the Laplacian stand-in: 10 smallest with a host ILU."""
+    """Preconditioned mode of config 3 on the Laplacian stand-in: 10 smallest with the ILUT preconditioner."""
     from raleigh_amd.interfaces import partial_hevp
-    from raleigh_amd.algebra.hip.host_ops import IncompleteLU
+    from raleigh_amd.algebra.hip.precond import IncompleteLU
     from oracle.sparse import lap3d
     k = known(golden_dir)['hevp_lap30_ilu10']
     A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
@@ -323,44 +323,6 @@ def test_bf16_storage_chebyshev_preconditioner():
         its[storage] = partial_hevp.last['iterations']
     assert _lib.library().calls.get('spmm_cheb_bf16', 0) > 10
     assert its['bf16'] <= its[None] + 3
-
-
-def test_jacobi_sweep_ilu_preconditioner():
-    """ILU factors from the host, applied on the device by Jacobi sweeps of the sparse kernel:
-    converges to the exact triangular solves with the number of sweeps, leaves its input alone,
-    and as a preconditioner of the eigensolver gives the same eigenvalues in fewer iterations."""
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as sla
-    from raleigh_amd.interfaces import partial_hevp
-    from raleigh_amd.core.solver import Options
-    from raleigh_amd.algebra.hip import Vectors
-    from raleigh_amd.algebra.hip.precond import JacobiSweepILU
-    from oracle.sparse import lap3d, lap3d_eigenvalues
-    A = lap3d(12, 11, 10, 1.0, 1.01, 1.02)
-    n = A.shape[0]
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((3, n))
-    ilu = sla.spilu(sp.csc_matrix(A), drop_tol=1e-4, fill_factor=10.0, permc_spec='NATURAL', diag_pivot_thresh=0.0)
-    L, d = sp.csr_matrix(ilu.L), ilu.U.diagonal()            # the operator is (L D L^T)^-1 for a symmetric matrix
-    ref = sla.spsolve_triangular(sp.csr_matrix(L.T), (sla.spsolve_triangular(L, x.T, lower=True).T / d).T, lower=False).T
-    errs = []
-    for sweeps in (2, 6, 40):
-        X, Y = Vectors(x), Vectors(n, 3)
-        JacobiSweepILU(A, sweeps=sweeps).apply(X, Y)
-        errs.append(np.linalg.norm(Y.data() - ref) / np.linalg.norm(ref))
-        assert np.array_equal(X.data(), x)
-    assert errs[0] > errs[1] > errs[2] and errs[2] < 1e-10
-    ana = lap3d_eigenvalues(12, 11, 10, 1.0, 1.01, 1.02, 4)
-    its = {}
-    for name, T in (('none', True), ('ilu', JacobiSweepILU(A, sweeps=6, drop_tol=1e-2, fill_factor=2.0))):
-        np.random.seed(1)
-        opt = Options()
-        opt.max_iter = 2000
-        lmd, xx, status = partial_hevp(A, T=T, which=4, tol=1e-7, verb=-1, opt=opt)
-        assert status == 0
-        assert np.max(np.abs(lmd[:4] - ana) / ana) < 1e-10
-        its[name] = partial_hevp.last['iterations']
-    assert its['ilu'] * 1.5 < its['none']
 
 
 def test_host_round_trips_per_iteration(fake, monkeypatch):
