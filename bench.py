@@ -8,11 +8,15 @@ BASELINE.json), m = 32, fp64, A = 7-point 3-D Laplacian.
 
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the rows
 are sharded over the ranks, every Gram / dots carries one all-reduce, the SpMM
-one halo exchange.  `--scaling weak` (default): every GPU holds a 215^3-row shard
-(the grid grows along z: 215 x 215 x 215 N), per-GPU work is fixed and `value` is the
-aggregate over the N GPUs.  `--scaling strong`: the 215^3 rows are split over the N
-ranks (the north-star's ">= 6x at 8 GPUs at n = 10M" question); at N = 1 the two are
-the same workload.  With N > 1 the run also reports the other mode under "also".
+one halo exchange.  `--scaling strong` (default): the 215^3 rows are split over the N
+ranks -- the north-star's ">= 6x at 8 GPUs at n = 10M" question; `value` is the whole
+job's rate, so value(N) / value(1) is the speed-up.  `--scaling weak`: every GPU holds a
+215^3-row shard (the grid grows along z: 215 x 215 x 215 N), per-GPU work is fixed and
+`value` is the aggregate over the N GPUs.  At N = 1 the two are the same workload; with
+N > 1 the run also reports the other mode under "also", the strong figure of the batched
+(5 round trips) iteration under "fused", the measured latency of one reduction round trip
+under "collectives", and BASELINE config 4 (pca of a row-sharded 62 500 N x 40 000 matrix)
+under "config4".
 
 Prints ONE JSON line (rank 0).  `value` = algorithmic GB/s of the whole job:
 bytes of SURVEY 8(d) (9 Gram calls = 16 blocks, 4 self-dots = 4 blocks, one
@@ -26,6 +30,7 @@ beside it.
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -431,6 +436,52 @@ def config_legs(L):
     return out
 
 
+def config4_sharded(L, comm, rows_per_gpu=62500, Nn=40000, r=1280, npc=1000, m=128):
+    """BASELINE config 4 on the sharded path: pca of a (rows_per_gpu x world) x 40 000 fp32 matrix, 1000 components, rows
+    sharded over the ranks (at 8 GPUs: the 500 000 x 40 000 of BASELINE.json), every shard built in HBM from factors with
+    known singular values; the transposed product's N x k all-reduce runs in column chunks behind the next chunk's GEMM."""
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    from raleigh_amd.algebra.hip.dist import ShardedAMatrix
+    from raleigh_amd.interfaces import pca
+    world, rank, M = comm.size, comm.rank, rows_per_gpu
+    rng = np.random.default_rng(4)                           # the right factor and the spectrum: the same on every rank
+    V = rng.standard_normal((Nn, r)).astype(np.float32)
+    V, _ = np.linalg.qr(V)
+    s = np.sort(rng.random(Nn).astype(np.float32)) ** (-0.75)
+    s = (s / s[0])[:r]
+    rng = np.random.default_rng(100 + rank)                  # this rank's rows of the left factor: orthonormal columns, the
+    U = rng.standard_normal((M, r)).astype(np.float32)       # first one constant => stacked: sqrt(world) x orthonormal
+    U[:, 0] = 1.0
+    U, _ = np.linalg.qr(U)
+    rows = Vectors(Nn, M, data_type=np.float32)
+    Matrix(np.ascontiguousarray(V)).apply(Vectors(np.ascontiguousarray(U * s)), rows)      # rows = (U s) V^T
+    del U, V
+    A4 = ShardedAMatrix(rows, comm)
+    op4 = A4.as_operator()
+    x, w = op4.new_vectors(Nn, m), op4.new_vectors(Nn, m)
+    y = op4.new_vectors(M * world, m)
+    x.fill_random()
+
+    def pair():
+        op4.apply(x, y)
+        op4.apply(y, w, transp=True)
+    t = max(timed_calls(L, pair, 5), 1e-6)              # (the rehearsal's stand-in timer reads 0)
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    mean, trans, comps = pca(A4, npc=npc)
+    el = time.perf_counter() - t0
+    sv = np.linalg.norm(trans, axis=0)
+    exact = math.sqrt(world) * s[1:npc + 1]
+    return {'workload': 'pca of a %d x %d fp32 matrix, %d components, rows sharded over %d GPU(s) (%d rows = %.1f GB per GPU, '
+                        'built on the device)' % (M * world, Nn, npc, world, M, M * Nn * 4 / 1e9),
+            'dense_pair_ms': round(t, 3), 'dense_pair_tflops_per_gpu': round(4.0 * M * Nn * m / t / 1e9, 1),
+            'dense_pair_frac_of_fp32_mfma_peak_157.3': round(4.0 * M * Nn * m / t / 1e9 / 157.3, 4),
+            'allreduce_bytes_per_product': Nn * m * 4, 'allreduce_chunks': int(op4.reduce_chunks),
+            'seconds': round(el, 3), 'iterations': int(pca.last['iterations']),
+            'operator_seconds': round(float(pca.last['operator_time']), 3),
+            'max_sigma_error_over_sigma_max': float(np.max(np.abs(sv - exact)) / exact[0])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -438,9 +489,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--side', type=int, default=215, help='lap3d side (n = side^3)')
     ap.add_argument('--m', type=int, default=32)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-configs', action='store_true', help='skip the config 2 / 3 / 5 legs (N = 1 only)')
+    ap.add_argument('--no-configs', action='store_true', help='skip the config legs (2 / 3 / 5 / one config-4 shard at N = 1, the '
+                                                            'row-sharded config 4 on the sharded path)')
     ap.add_argument('--force-dist', action='store_true',
                     help='use the sharded (torch.distributed / RCCL) code path even with one rank, all-reduce and '
                          'halo exchange included (a rank then exchanges with itself)')
@@ -485,6 +537,8 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors, partition
         comm = Comm(force_collectives=True if args.force_dist else None)
+        # (forced at one rank: the rows a real pair of neighbours would trade -- two planes of the grid -- not half the shard)
+        comm.forced_halo_rows = 2 * args.side * args.side
     L = _lib.lib(local_rank)
     side, m, es = args.side, args.m, 8
 
@@ -621,7 +675,9 @@ def main():
             traffic = None
     roofline = {'bound': 'hbm', 'kernel': 'gram_stream_kernel<double, 256, 32> (X.dot(Y), m=k=%d)' % m,
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'traffic_from_profile': traffic,
+                'traffic_note': 'PMC counters cannot be read inside this process: hbm_bytes_per_launch of the same kernel on the same '
+                                'shape from profiles/gram_traffic.json (rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE)',
                 'algorithmic_bytes_per_launch': main_res['gram_bytes'], 'avg_launch_ms': round(main_res['gram_ms'], 4),
                 'inner_iteration_frac': round(main_res['value'] / world / HBM_PEAK_GBS, 4),
                 'device_copy_ceiling_gbs': round(main_res.get('copy_gbs', 0.0), 1),
@@ -641,7 +697,19 @@ def main():
     if also is not None:
         out['also'] = also
     if comm is not None:
-        out['collectives'] = {'backend': 'nccl (RCCL)', 'forced_at_one_rank': bool(args.force_dist)}
+        # one reduction round trip as every dot / dots makes it: all-reduce of an m x m block on the kernels' stream + the
+        # fetch of the result to the host (no kernel in front of it)
+        buf = comm.reduction_buffer(m * m * es)
+        comm.allreduce_from_device(buf, np.float64, m * m)
+        trips = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            comm.allreduce_from_device(buf, np.float64, m * m)
+            trips.append(time.perf_counter() - t0)
+        out['collectives'] = {'backend': 'gloo (rehearsal)' if rehearsal else 'nccl (RCCL)', 'forced_at_one_rank': bool(args.force_dist),
+                              'round_trips_per_step': {'headline': 13, 'fused': 5},
+                              'round_trip_us': round(max_over_ranks(float(np.median(trips))) * 1e6, 1),
+                              'what': 'median wall time of one all-reduce(m x m fp64) + result fetch, max over ranks'}
 
     def guarded(key, fn):
         """A failure on ANY rank is agreed on by all of them (the others would otherwise wait in the next
@@ -661,6 +729,11 @@ def main():
     ok = True
     if args.solve_side > 0:
         ok = guarded('solve', lambda: solve_ten(args.solve_side, comm)) and ok
+    if comm is not None and not args.no_configs:
+        if rehearsal:        # (the control flow of the leg at toy size)
+            ok = guarded('config4', lambda: config4_sharded(L, comm, rows_per_gpu=192, Nn=96, r=24, npc=8, m=8)) and ok
+        else:
+            ok = guarded('config4', lambda: config4_sharded(L, comm)) and ok
     if world == 1 and comm is None:
         if args.ilu_side > 0:
             ok = guarded('solve_ilu', lambda: solve_ilu_pair(args.ilu_side)) and ok

@@ -62,6 +62,7 @@ class Comm:
             self.device = torch.device('cpu')
         self._red = None
         self._views = {}
+        self.forced_halo_rows = None       # (forced one-rank runs: how many own rows take the halo path; None = half)
 
     def buffer(self, nbytes):
         """A communication buffer (device memory under RCCL, host memory under gloo)."""
@@ -303,9 +304,12 @@ class ShardedSparseMatrix:
         cols = loc.indices.astype(np.int64)
         own = (cols >= r0) & (cols < r1)
         if comm.size == 1 and comm.force:
-            # one rank exchanging with itself: the second half of the own rows is also fetched through
-            # the halo path (pack -> send to self -> receive -> halo block), so the whole exchange runs
-            own = cols < r0 + (r1 - r0) // 2
+            # one rank exchanging with itself: the last rows of the shard (half of them, or comm.forced_halo_rows:
+            # e.g. the two boundary planes a real neighbour pair would trade) are also fetched through the halo
+            # path (pack -> send to self -> receive -> halo block), so the whole exchange runs
+            h = getattr(comm, 'forced_halo_rows', None)
+            h = (r1 - r0) // 2 if h is None else max(1, min(int(h), r1 - r0))
+            own = cols < r0 + ((r1 - r0 - h) // 8) * 8
         halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
         owner = np.searchsorted(off, halo_cols, side='right') - 1
         # local column numbering: own rows first, then the halo rows from a multiple of 8 on (the
@@ -479,10 +483,16 @@ class ShardedDenseMatrix:
 
     def __init__(self, local_rows, comm, offsets=None, global_rows=None):
         from .matrix import Matrix
-        local_rows = np.ascontiguousarray(local_rows)
         self._comm = comm
-        self._loc = Matrix(local_rows)
-        mloc, n = local_rows.shape
+        if isinstance(local_rows, Matrix):         # this rank's rows already in HBM (e.g. built on the device)
+            self._loc = local_rows
+        elif isinstance(local_rows, Vectors):
+            self._loc = Matrix(local_rows)
+        else:
+            self._loc = Matrix(np.ascontiguousarray(local_rows))
+        if self._loc.order() != 'C_CONTIGUOUS':
+            raise ValueError('the local rows of a row-sharded matrix must be C-contiguous')
+        mloc, n = self._loc.shape()
         counts = [None] * comm.size
         comm.dist.all_gather_object(counts, int(mloc), group=comm.group)
         off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
@@ -492,7 +502,15 @@ class ShardedDenseMatrix:
         self._shape = (int(off[-1]), n)
         if global_rows is not None:
             assert global_rows == self._shape[0]
-        self._dtype = local_rows.dtype.type
+        self._dtype = self._loc.data_type()
+        self._chunk_bufs = {}
+        self.reduce_chunks = 4          # column chunks of A_p whose all-reduce overlaps the next chunk's product
+        self.chunk_min_cols = 1024      # ... when every chunk keeps at least this many columns
+        self.round_trips = 0
+
+    # the rank-one epilogue is local for y = A x - u c^T (every rank subtracts its own rows of u c^T); the transposed
+    # product would need the term once, after the reduction: not offered (interfaces/pca.py then takes the unfused steps)
+    r1_transposed = False
 
     @classmethod
     def from_global(cls, a, comm):
@@ -544,6 +562,10 @@ class ShardedDenseMatrix:
         return float(t.cpu().numpy()[0])
 
     def apply(self, x, y, transp=False):
+        self.apply_r1(x, y, transp)
+
+    def apply_r1(self, x, y, transp=False, u=None, c=None):
+        """y = Op(A) x (- u c^T for the non-transposed product: Matrix.apply_r1; u None = ones)."""
         m, n = self._shape
         k = x.nvec()
         if k != y.nvec():
@@ -553,22 +575,51 @@ class ShardedDenseMatrix:
                 raise ValueError('apply needs replicated input and row-sharded output vectors')
             if x.dimension() != n or y.dimension() != m:
                 raise ValueError('Matrix and vectors dimensions incompatible')
-            self._loc.apply(x, _LocalView(y), False)
+            if u is not None and not isinstance(u, ShardedVectors):
+                raise ValueError('the rank-one vector must be row-sharded like the result')
+            self._loc.apply_r1(x, _LocalView(y), False, None if u is None else _LocalView(u), c)
             return
+        if c is not None:
+            raise ValueError('the transposed product of a row-sharded matrix takes no rank-one term')
         if not isinstance(x, ShardedVectors) or isinstance(y, ShardedVectors):
             raise ValueError('apply(transp=True) needs row-sharded input and replicated output vectors')
         if x.dimension() != m or y.dimension() != n:
             raise ValueError('Matrix and vectors dimensions incompatible')
-        c, L = self._comm, _lib.lib()
+        cm, L = self._comm, _lib.lib()
         es = y._es
-        buf = c.reduction_buffer(n * k * es)
-        _lib.check(L.rlh_dense_apply(y._code, self._loc.shape()[0], n, self._loc.data_ptr(), self._loc.lda(), 0, 1, k,
-                                     x.data_ptr(), x.ld(), buf.data_ptr(), n))
+        mloc = self._loc.shape()[0]
         real = np.dtype(_REAL[np.dtype(self._dtype).type])
-        tdt = c.torch.float32 if real == np.float32 else c.torch.float64
-        nreal = n * k * (2 if np.dtype(self._dtype).kind == 'c' else 1)
-        c.dist.all_reduce(buf[:nreal * real.itemsize].view(tdt), group=c.group)
-        _lib.check(L.rlh_copy(y._code, n, k, buf.data_ptr(), n, y.data_ptr(), y.ld()))
+        tdt = cm.torch.float32 if real == np.float32 else cm.torch.float64
+        per_elem = 2 if np.dtype(self._dtype).kind == 'c' else 1
+        reduce_ = cm.size > 1 or cm.force
+        # y = sum_p A_p^H x_p in column chunks of A_p (= row chunks of y): the all-reduce of chunk i runs on RCCL's
+        # stream while the matrix cores work on chunk i + 1; every element of A_p is still read once
+        nch = self.reduce_chunks if (reduce_ and n >= self.chunk_min_cols * self.reduce_chunks) else 1
+        step = -(-n // nch)
+        step = -(-step // 16) * 16
+        pending = []
+        for i in range(nch):
+            j0, j1 = i * step, min(n, (i + 1) * step)
+            if j1 <= j0:
+                break
+            nc = j1 - j0
+            key = (i, nc, k, es)
+            buf = self._chunk_bufs.get(key)
+            if buf is None:
+                if len(self._chunk_bufs) > 16:
+                    self._chunk_bufs.clear()
+                buf = self._chunk_bufs[key] = cm.buffer(nc * k * es)
+            _lib.check(L.rlh_dense_apply(y._code, mloc, nc, self._loc.data_ptr() + j0 * es, self._loc.lda(), 0, 1, k,
+                                         x.data_ptr(), x.ld(), buf.data_ptr(), nc))
+            work = None
+            if reduce_:
+                work = cm.dist.all_reduce(buf[:nc * k * per_elem * real.itemsize].view(tdt), group=cm.group, async_op=True)
+                self.round_trips += 1
+            pending.append((j0, nc, buf, work))
+        for j0, nc, buf, work in pending:
+            if work is not None:
+                work.wait()
+            _lib.check(L.rlh_copy(y._code, nc, k, buf.data_ptr(), nc, y.data_ptr() + j0 * es, y.ld()))
 
 
 class _LocalView:
@@ -588,6 +639,7 @@ class ShardedAMatrix:
     """Counterpart of AMatrix (raleigh/algebra/dense_matrix.py) for a row-sharded data matrix."""
 
     def __init__(self, local_rows, comm, offsets=None):
+        """local_rows: this rank's rows as an ndarray, or already in HBM as a Matrix / Vectors (one vector per row)."""
         self.__op = ShardedDenseMatrix(local_rows, comm, offsets)
         self.__comm = comm
 

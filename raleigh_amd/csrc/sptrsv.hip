@@ -937,7 +937,7 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
       nlev = std::max(nlev, l + 1);
     }
   };
-  // what the transform is for is fewer levels: where it removes less than 30 % of them (a 7-point stencil: its chains
+  // what the transform is for is fewer levels: where it removes less than a quarter of them (a 7-point stencil: its chains
   // along x are not what makes its factors deep) the extra entries cost more than the levels saved
   {
     int32_t plain = 0;
@@ -952,7 +952,7 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     t->levels_plain = plain;
     const int B = block_limit();
     transform(B);
-    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.7 * (double)plain) transform(1);
+    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.75 * (double)plain) transform(1);
   }
   t->lev_off.assign((size_t)nlev + 1, 0);
   for (int64_t i = 0; i < n; ++i) t->lev_off[(size_t)level[(size_t)i] + 1]++;

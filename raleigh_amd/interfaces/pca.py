@@ -61,7 +61,8 @@ class _OperatorSVD:
         # vectors are created by the OPERATOR so that a row-sharded matrix can hand out
         # sharded vectors for its row dimension and replicated ones for its column dimension
         self.w = self.op.new_vectors(n if transp else m, 0)
-        self._fused = hasattr(self.op, 'apply_r1')
+        # (a row-sharded matrix folds the rank-one term into the non-transposed product only: dist.ShardedDenseMatrix)
+        self._fused = hasattr(self.op, 'apply_r1') and (not transp or getattr(self.op, 'r1_transposed', True))
         self._coef = None
         if (mean is not None or deflate is not None) and not (self._fused and shift):
             raise ValueError('a given mean / a deflated operator need a Matrix with apply_r1 and shift')

@@ -164,6 +164,23 @@ def main():
     Ad.apply(Yv, W, transp=True)
     ref2 = ops.dense_apply(a, ref, True)
     assert np.linalg.norm(W.data() - ref2) < 1e-4 * np.linalg.norm(ref2)
+    # the same product in three column chunks whose all-reduces overlap the next chunk's product (at config-4 sizes the
+    # default; forced here), and the rank-one epilogue of the non-transposed product on the local rows
+    Ad.reduce_chunks, Ad.chunk_min_cols = 3, 16
+    trips = Ad.round_trips
+    W2 = Ad.new_vectors(57, 4)
+    Ad.apply(Yv, W2, transp=True)
+    assert Ad.round_trips - trips == (2 if size > 1 else 0)      # 57 columns in chunks of 32 (16-column granularity)
+    assert np.linalg.norm(W2.data() - ref2) < 1e-4 * np.linalg.norm(ref2)
+    from raleigh_amd.algebra.hip.matrix import coefficients_into
+    from raleigh_amd.algebra.hip.memory import DeviceBuffer
+    cvec = Vectors(rng.standard_normal((1, 57)).astype(np.float32))
+    cbuf = DeviceBuffer(64, zero=False)
+    coefficients_into(cbuf.ptr, X, cvec)                       # c_j = <x_j, cvec>
+    Y2 = Ad.new_vectors(203, 4)
+    Ad.apply_r1(X, Y2, False, None, cbuf.ptr)                  # A x - e c^T
+    ref3 = ref - (x @ cvec.data()[0])[:, None]
+    assert np.linalg.norm(Y2.data() - ref3) < 1e-5 * np.linalg.norm(ref3)
     assert abs(Ad.frobenius2() - float(np.sum(a.astype(np.float64) ** 2))) < 1e-3 * np.sum(a ** 2)
     np.random.seed(1)
     A, sigma, u, v = generate(400, 150, 60, pca=True)

@@ -27,8 +27,11 @@ def test_two_rank_bench_line():
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
         assert key in d
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 2
-    assert d['config']['n'] == 12 * 12 * 24                # weak: the grid grows along z with the ranks
-    assert d['also']['scaling'] == 'strong' and d['also']['n'] == 12 ** 3
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 2
+    assert d['config']['n'] == 12 ** 3                     # strong (the default): the same rows split over the ranks
+    assert d['also']['scaling'] == 'weak' and d['also']['n'] == 12 * 12 * 24     # weak: the grid grows along z
+    assert d['collectives']['round_trips_per_step'] == {'headline': 13, 'fused': 5} and d['collectives']['round_trip_us'] > 0
+    c4 = d['config4']                                      # the row-sharded PCA leg (toy size under the rehearsal)
+    assert 'error' not in c4 and c4['max_sigma_error_over_sigma_max'] < 5e-3 and c4['iterations'] > 0
     assert d['solve']['status'] == 0 and d['solve']['max_rel_eigenvalue_error'] < 1e-9
     assert 'cpu_baseline' not in d and 'configs' not in d  # N = 1 only

@@ -101,3 +101,42 @@ def test_sharded_driver_with_forced_collectives(comm):
                                   vectors=lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm))
     assert status == 0
     assert np.allclose(lmd[:6], lap3d_eigenvalues(30, 30, 30, 1.0, 1.01, 1.02, 6), rtol=1e-10)
+
+
+def test_sharded_pca_matches_single_gpu(comm):
+    """BASELINE config 4's layout on hardware with the collectives forced: the row-sharded dense operator (rows built
+    in HBM, rank-one epilogue on the local rows, the transposed product reduced in column chunks whose all-reduce
+    overlaps the next chunk's GEMM) under pca() against the plain single-GPU path on the same data, and the two
+    products against the oracle."""
+    from raleigh_amd.algebra.hip import Vectors
+    from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix
+    from raleigh_amd.interfaces import pca
+    from oracle.pca_data import generate
+    np.random.seed(1)
+    A, sigma, u, v = generate(3000, 4200, 300, dtype=np.float32, pca=True)
+    rows = Vectors(np.ascontiguousarray(A))                       # this rank's rows, one vector per row, in HBM
+    Ad = ShardedDenseMatrix(rows, comm)
+    assert Ad.shape() == (3000, 4200)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((8, 4200)).astype(np.float32)
+    X, Y = Vectors(x), Ad.new_vectors(3000, 8)
+    Ad.apply(X, Y)
+    ref = ops.dense_apply(A, x)
+    assert rel(Y.data(), ref) < 1e-5
+    W = Ad.new_vectors(4200, 8)
+    trips = Ad.round_trips
+    Ad.apply(Y, W, transp=True)
+    assert Ad.round_trips - trips == 4                            # four overlapped chunk reductions (RCCL, to itself)
+    assert rel(W.data(), ops.dense_apply(A, ref, True)) < 1e-4
+    np.random.seed(1)
+    mean, trans, comps = pca(ShardedAMatrix(rows, comm), npc=40)
+    np.random.seed(1)
+    mean1, trans1, comps1 = pca(A, npc=40)
+    sv, sv1 = np.linalg.norm(trans, axis=0), np.linalg.norm(trans1, axis=0)
+    exact = np.linalg.svd((A - A.mean(axis=0, keepdims=True)).astype(np.float64), compute_uv=False)[:40]
+    assert np.max(np.abs(sv - exact)) <= 1e-3 * exact[0] and np.max(np.abs(sv1 - exact)) <= 1e-3 * exact[0]
+    assert np.max(np.abs(sv - sv1)) <= 1e-3 * exact[0]
+    assert rel(mean, mean1) < 1e-5
+    # the same subspace: the leading 30 components of one lie in the span of the other's 40
+    c = np.linalg.svd(comps[:30] @ comps1.T, compute_uv=False)
+    assert c.min() > 1 - 1e-3
