@@ -407,41 +407,105 @@ class Vectors:
         return self.new_vectors(q)
 
     def svd(self):
-        """Thin SVD in place: self (as an n x m matrix) = W diag(sigma) V^T with W
-        orthonormal replacing self; returns (sigma, conj(V)) like
-        dense_numpy.py:125-128 / dense_cublas.py:537-591 (gesvd 'O').
+        """Thin SVD in place: self (as an n x m matrix) = W diag(sigma) V^H with W orthonormal replacing
+        self; returns (sigma, V) like dense_numpy.py:125-128 / dense_cublas.py:537-591 (gesvd 'O').
 
-        Device algorithm: two passes of scaled Gram + host eigh + block update
-        (the second pass removes the squared-condition loss of the first),
-        then a small host SVD of the accumulated m x m factor."""
+        The solver calls it exactly when the block has lost rank (raleigh/core/solver.py:877-885), so the
+        algorithm must survive that: a rank-revealing block Gram-Schmidt built from the block operations
+        (every pass over the n x m data is a Gram or a block update on the device; all m x m algebra on the
+        host in double precision).  Invariant: original = W T.  Per round, on the columns not yet finished:
+          1. rotate them by the eigenvectors of their Gram matrix (descending energy);
+          2. peel those whose energy lies within `theta` of the round's largest -- their mutual
+             orthogonality is accurate to eps / theta -- remove what they still carry of the finished
+             columns, and orthonormalise them by two Cholesky-QR passes;
+          3. remove them from the remaining columns (twice) and go on with the rest, which is smaller by
+             sqrt(theta): no quantity is ever formed as a difference of squares of very different sizes,
+             which is what limits a single Gram pass to cond < eps^-1/2.
+        Columns whose energy has fallen to rounding level are dropped from T (an error of eps sigma_max in
+        the reconstruction) and replaced by random directions orthonormalised against the rest, so W is
+        orthonormal whatever the rank.  Last, T = Ur S V^H on the host and W <- W Ur."""
         import scipy.linalg as sla
         m = self.nvec()
         real_dt = np.float32 if self._dtype in (np.float32, np.complex64) else np.float64
+        wide = np.complex128 if self._is_complex else np.float64
         if m < 1:
             return np.zeros((0,), dtype=real_dt), np.zeros((0, 0), dtype=self._dtype)
-        w = self.new_vectors(m)
-        T = np.eye(m, dtype=np.complex128 if self._is_complex else np.float64)
-        src, dst = self, w
-        for _ in range(2):
-            G = src.dot(src).astype(T.dtype)
-            d = np.sqrt(np.abs(np.real(np.diag(G))))
-            d[d == 0] = 1.0
-            Gs = (G / d[:, None]) / d[None, :]
-            lam, P = sla.eigh((Gs + Gs.conj().T) / 2)
-            lam = np.maximum(lam, np.finfo(real_dt).eps * max(lam[-1], 0.0) + np.finfo(np.float64).tiny)
-            # G[i,j] = <x_i, x_j> = (X^H X)[i,j]  =>  X (D^-1 P lam^-1/2) has orthonormal columns
-            Ti = (P / np.sqrt(lam)[None, :]) / d[:, None]
-            src.multiply(Ti.astype(self._dtype), dst)
-            T = T @ Ti
-            src, dst = dst, src
-        # self_original = src * R with R = T^-1 ; R = Ur S Vr^H
-        R = np.linalg.inv(T)
-        Ur, S, Vrh = np.linalg.svd(R)
-        src.multiply(Ur.astype(self._dtype), dst)
-        if dst is not self:
-            dst.copy(self)
-        # X = W S Vr^H = W S v^T  =>  v = conj(Vr); the reference returns conj(v) = Vr
-        return S.astype(real_dt), Vrh.conj().T.astype(self._dtype)
+        f0 = self.selected()[0]
+        eps = float(np.finfo(real_dt).eps)
+        theta = 1e-6 if real_dt == np.float64 else 1e-3
+        work = self.new_vectors(m)
+        T = np.eye(m, dtype=wide)
+        herm = lambda g: (g.astype(wide) + g.astype(wide).conj().T) / 2
+
+        def right_multiply(block, q):                     # block <- block q (q square, host)
+            k = block.nvec()
+            work.select(k)
+            block.multiply(np.ascontiguousarray(q.astype(self._dtype)), work)
+            work.copy(block)
+
+        def remove(block, basis, rows_block, rows_basis):  # block -= basis (basis^H block), T follows
+            for _ in range(2):
+                c = block.dot(basis).astype(wide)
+                block.add(basis, -1.0, c.astype(self._dtype))
+                T[rows_basis, :] += c @ T[rows_block, :]
+
+        def orthonormalise(block, rows):                   # two Cholesky-QR passes; False: not positive definite
+            for _ in range(2):
+                g = herm(block.dot(block))
+                try:
+                    r = sla.cholesky(g, lower=False)
+                except sla.LinAlgError:
+                    return False
+                right_multiply(block, sla.solve_triangular(r, np.eye(r.shape[0], dtype=wide), lower=False))
+                if rows is not None:
+                    T[rows, :] = r @ T[rows, :]
+            return True
+
+        done, top = 0, None
+        fin, act, new = self.reference(), self.reference(), self.reference()
+        while done < m:
+            a = m - done
+            act.select(a, f0 + done)
+            lam, P = sla.eigh(herm(act.dot(act)))
+            lam, P = lam[::-1], P[:, ::-1]
+            if top is None:
+                top = max(float(lam[0]), np.finfo(np.float64).tiny)
+            if lam[0] <= (8 * eps) ** 2 * m * top:
+                # nothing but rounding noise left: these directions do not belong to the block's range
+                T[done:, :] = 0
+                for _ in range(3):
+                    act.fill_random()
+                    if done > 0:
+                        fin.select(done, f0)
+                        for _ in range(2):
+                            act.add(fin, -1.0, act.dot(fin))
+                    if orthonormalise(act, None):
+                        break
+                done = m
+                break
+            k = max(1, int(np.sum(lam >= theta * lam[0])))
+            right_multiply(act, P)
+            T[done:, :] = P.conj().T @ T[done:, :]
+            new.select(k, f0 + done)
+            if done > 0:
+                fin.select(done, f0)
+                remove(new, fin, slice(done, done + k), slice(0, done))
+            if not orthonormalise(new, slice(done, done + k)):
+                # (cannot happen for columns within theta of each other; keep going on the eigen-scaling alone)
+                d = np.sqrt(np.maximum(np.abs(np.real(new.dots(new))), np.finfo(np.float64).tiny)).astype(np.float64)
+                new.scale(d.astype(real_dt))
+                T[done:done + k, :] = d[:, None] * T[done:done + k, :]
+            if k < a:
+                act.select(a - k, f0 + done + k)
+                remove(act, new, slice(done + k, m), slice(done, done + k))
+            done += k
+        self.select(m, f0)
+        Ur, S, Vh = np.linalg.svd(T)
+        work.select(m)
+        self.multiply(np.ascontiguousarray(Ur.astype(self._dtype)), work)
+        work.copy(self)
+        # X = W S V^H; the reference hands back conj(v) of numpy's data = v S w, i.e. V
+        return S.astype(real_dt), np.ascontiguousarray(Vh.conj().T.astype(self._dtype))
 
 
 class ReductionBatch:
