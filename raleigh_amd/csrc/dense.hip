@@ -9,8 +9,8 @@
 // floats so the per-lane fragment reads (32 rows x 1 k) are bank-conflict free.  The vector
 // index rides the MFMA row and the output-row index rides the MFMA column (= lane & 31), so
 // each accumulator register stores as 128-byte contiguous runs of the column-major Y.
-// Other dtypes (f64, complex): generic LDS-tiled VALU kernel (parity path; the BASELINE dense
-// configurations are fp32).
+// Other dtypes (f64, complex): dense_mfma16_kernel on the 16x16x4 matrix-core shapes (real planes); the generic
+// LDS-tiled VALU kernel remains for unaligned layouts.
 #include <stdlib.h>
 
 #include "common.h"
@@ -483,6 +483,195 @@ __global__ __launch_bounds__(256) void dense_valu_kernel(DenseArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- double / complex on the matrix cores
+// The reference runs s / d / c / z through the same gemm (dense_cublas.py:732-776); here float has the two tuned
+// kernels above, and double, complex double and complex float share this one: v_mfma_f64_16x16x4_f64 (or
+// v_mfma_f32_16x16x4_f32: the same shape) on REAL planes.  A complex tile is split into its re and im planes on
+// its way into the LDS and the product becomes four real ones per k-step (conj(A): the sign of the im plane).
+//  * C^T tile of 64 vectors x 64 output rows per 256-thread workgroup (four waves of 32 x 32 = 2 x 2 MFMA tiles),
+//    BK = 16, LDS double buffered, loads of step t + 1 in flight during the MFMAs of step t;
+//  * LDS planes [index][18] elements: a fragment read (lane l: index l % 16, k = l / 16) then falls into 32
+//    different 8-byte slots per half-wave (row stride = 2 mod 32), and a 16-byte piece of two consecutive k goes
+//    in with one ds_write_b128;
+//  * the vector index rides the MFMA row and the output row the MFMA column (lane % 16), so an accumulator
+//    register stores as 128-byte runs of the column-major Y.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <typename R> struct Acc4;
+template <> struct Acc4<double> { using V = f64x4; };
+template <> struct Acc4<float> { using V = f32x4; };
+
+template <typename T, typename R, bool CPLX, bool A_KC, bool CONJ, int TR, int TV>
+__global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
+  constexpr int MR = 32 * TR, BN = 32 * TV, BK = 16, SK = BK + 2;     // 2 x 2 waves of TR x TV MFMA tiles
+  constexpr int NP = CPLX ? 2 : 1;                  // planes
+  constexpr int EPU = 16 / (int)sizeof(T);          // elements of T per 16-byte unit
+  constexpr int UA = MR * BK / EPU / 256, UB = BN * BK / EPU / 256;   // units per thread and K step: A tile, X tile
+  static_assert(UA >= 1 && UB >= 1, "tile too small");
+  using V = typename Acc4<R>::V;
+  struct alignas(16) Unit { T e[EPU]; };
+  __shared__ __attribute__((aligned(16))) R ldsA[2][NP][MR * SK];
+  __shared__ __attribute__((aligned(16))) R ldsB[2][NP][BN * SK];
+  const T *__restrict__ A = (const T *)a.A;
+  const T *__restrict__ X = (const T *)a.X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves: output rows x vectors
+  const int64_t i0 = (int64_t)blockIdx.x * MR;
+  const int v0 = blockIdx.y * BN;
+  Unit ra[UA], rb[UB];
+  auto zero_unit = [](Unit &u) {
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) u.e[e] = zero_of(T{});
+  };
+  auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+    for (int q = 0; q < UA; ++q) {
+      const int u = tid + q * 256;
+      if (A_KC) {                                   // EPU consecutive k of one output row
+        const int r = u / (BK / EPU), kq = (u % (BK / EPU)) * EPU;
+        int64_t i = i0 + r;
+        i = i < a.ny ? i : a.ny - 1;                // clamped rows are computed but never stored
+        const int64_t k = k0 + kq;
+        const int64_t kc = (k + EPU <= a.lda) ? k : 0;
+        ra[q] = *reinterpret_cast<const Unit *>(A + i * a.lda + kc);
+#pragma unroll
+        for (int e = 0; e < EPU; ++e)
+          if (k + e >= a.nx) ra[q].e[e] = zero_of(T{});
+      } else {                                      // EPU consecutive output rows at one k
+        const int kk = u / (MR / EPU), rq = (u % (MR / EPU)) * EPU;
+        int64_t i = i0 + rq;
+        i = (i + EPU <= a.lda) ? i : 0;
+        const int64_t k = k0 + kk;
+        const int64_t kc = k < a.nx ? k : 0;
+        ra[q] = *reinterpret_cast<const Unit *>(A + kc * a.lda + i);
+        if (k >= a.nx) zero_unit(ra[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UB; ++q) {
+      const int u = tid + q * 256;
+      const int c = u / (BK / EPU), kq = (u % (BK / EPU)) * EPU;
+      int vc = v0 + c;
+      vc = vc < a.m ? vc : a.m - 1;
+      const int64_t k = k0 + kq;
+      const int64_t kc = (k + EPU <= a.ldx) ? k : 0;
+      rb[q] = *reinterpret_cast<const Unit *>(X + (int64_t)vc * a.ldx + kc);
+#pragma unroll
+      for (int e = 0; e < EPU; ++e)
+        if (k + e >= a.nx) rb[q].e[e] = zero_of(T{});
+    }
+  };
+  auto put = [](R *re, R *im, int at, const T &v) {          // one element into its plane(s)
+    if constexpr (CPLX) { re[at] = v.re; im[at] = v.im; } else { re[at] = v; (void)im; }
+  };
+  auto store_tiles = [&](int buf) {
+    R *are = ldsA[buf][0], *aim = ldsA[buf][NP - 1], *bre = ldsB[buf][0], *bim = ldsB[buf][NP - 1];
+#pragma unroll
+    for (int q = 0; q < UA; ++q) {
+      const int u = tid + q * 256;
+      if (A_KC) {
+        const int r = u / (BK / EPU), kq = (u % (BK / EPU)) * EPU;
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) put(are, aim, r * SK + kq + e, ra[q].e[e]);
+      } else {
+        const int kk = u / (MR / EPU), rq = (u % (MR / EPU)) * EPU;
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) put(are, aim, (rq + e) * SK + kk, ra[q].e[e]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < UB; ++q) {
+      const int u = tid + q * 256;
+      const int c = u / (BK / EPU), kq = (u % (BK / EPU)) * EPU;
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) put(bre, bim, c * SK + kq + e, rb[q].e[e]);
+    }
+  };
+  V acc[NP][TV][TR];                                 // [plane][vector tile][row tile]
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+    for (int tv = 0; tv < TV; ++tv)
+#pragma unroll
+      for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[pl][tv][tr][r] = (R)0;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int row0 = wm * 16 * TR, vec0 = wn * 16 * TV;
+  int buf = 0;
+  if (a.nx > 0) { load_tiles(0); store_tiles(0); }
+  __syncthreads();
+  for (int64_t k0 = 0; k0 < a.nx; k0 += BK) {
+    const bool more = (k0 + BK < a.nx);
+    if (more) load_tiles(k0 + BK);
+    const R *are = ldsA[buf][0], *aim = ldsA[buf][NP - 1], *bre = ldsB[buf][0], *bim = ldsB[buf][NP - 1];
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      R xr[TV], xi[TV], ar[TR], ai[TR];
+#pragma unroll
+      for (int t = 0; t < TV; ++t) {
+        xr[t] = bre[(vec0 + t * 16 + fi) * SK + ks * 4 + fk];
+        if constexpr (CPLX) xi[t] = bim[(vec0 + t * 16 + fi) * SK + ks * 4 + fk];
+      }
+#pragma unroll
+      for (int t = 0; t < TR; ++t) {
+        ar[t] = are[(row0 + t * 16 + fi) * SK + ks * 4 + fk];
+        if constexpr (CPLX) ai[t] = aim[(row0 + t * 16 + fi) * SK + ks * 4 + fk];
+      }
+#pragma unroll
+      for (int tv = 0; tv < TV; ++tv)
+#pragma unroll
+        for (int tr = 0; tr < TR; ++tr) {
+          acc[0][tv][tr] = mfma16(xr[tv], ar[tr], acc[0][tv][tr]);
+          if constexpr (CPLX) {
+            // op(A) = conj(A) for CONJ: (ar -/+ i ai)(xr + i xi)
+            acc[0][tv][tr] = mfma16(xi[tv], CONJ ? ai[tr] : -ai[tr], acc[0][tv][tr]);
+            acc[1][tv][tr] = mfma16(xi[tv], ar[tr], acc[1][tv][tr]);
+            acc[1][tv][tr] = mfma16(xr[tv], CONJ ? -ai[tr] : ai[tr], acc[1][tv][tr]);
+          }
+        }
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D[v][i]: column (lane % 16) = output row; the vector is the D row: 4 (lane / 16) + reg for the f32 shape,
+  // (lane / 16) + 4 reg for v_mfma_f64_16x16x4_f64 (its C/D map differs from every other shape's)
+  T *__restrict__ Y = (T *)a.Y;
+#pragma unroll
+  for (int tv = 0; tv < TV; ++tv)
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int v = v0 + vec0 + tv * 16 + (sizeof(R) == 8 ? (lane >> 4) + 4 * r : 4 * (lane >> 4) + r);
+        const int64_t i = i0 + row0 + tr * 16 + (lane & 15);
+        if (v < a.m && i < a.ny) {
+          T y;
+          if constexpr (CPLX) y = T{acc[0][tv][tr][r], acc[1][tv][tr][r]};
+          else y = acc[0][tv][tr][r];
+          Y[i + (int64_t)v * a.ldy] = r1_apply<T>(a, y, i, v);
+        }
+      }
+}
+
+template <typename T, typename R, bool CPLX, int TR, int TV>
+static int launch_mfma16(const DenseArgs &a) {
+  Context &c = ctx();
+  dim3 grid((unsigned)((a.ny + 32 * TR - 1) / (32 * TR)), (unsigned)((a.m + 32 * TV - 1) / (32 * TV)));
+  if (a.a_kcontig) {
+    if (a.conj_a) hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, true, true, TR, TV>), grid, dim3(256), 0, c.stream, a);
+    else hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, true, false, TR, TV>), grid, dim3(256), 0, c.stream, a);
+  } else {
+    if (a.conj_a) hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, false, true, TR, TV>), grid, dim3(256), 0, c.stream, a);
+    else hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, false, false, TR, TV>), grid, dim3(256), 0, c.stream, a);
+  }
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
 static int env_int_d(const char *name, int dflt) {
   const char *e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
@@ -580,6 +769,19 @@ static int dense_impl(const DenseArgs &a) {
       if (a.m > 64) return mr == 64 ? launch_mfma<64, 128>(a) : launch_mfma<128, 128>(a);
       if (a.m > 32) return launch_mfma<128, 64>(a);
       return launch_mfma<128, 32>(a);
+    }
+  }
+  if constexpr (DT != RLH_S) {
+    // double / complex: the matrix cores whenever 16-byte pieces can be loaded (RLH_DENSE_VALU=1 forces the VALU kernel)
+    constexpr int64_t EPU = 16 / (int64_t)sizeof(T);
+    const bool ok = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.X)) & 15u) == 0 && (a.lda % EPU == 0) &&
+                    (a.ldx % EPU == 0) && a.lda >= EPU && a.ldx >= EPU && a.nx > 0 && !env_int_d("RLH_DENSE_VALU", 0);
+    if (ok) {
+      // 64 rows x 64 vectors per workgroup (measured at 20000 x 20000 x 128 fp64: 33 TF against 27 TF for 64 x 128 tiles,
+      // whose 313 workgroups leave the second round of the 256 CUs a quarter full, and 13 TF for the VALU kernel)
+      if constexpr (DT == RLH_D) return launch_mfma16<double, double, false, 2, 2>(a);
+      if constexpr (DT == RLH_Z) return launch_mfma16<c64, double, true, 2, 2>(a);
+      if constexpr (DT == RLH_C) return launch_mfma16<c32, float, true, 2, 2>(a);
     }
   }
   dim3 grid((unsigned)((a.ny + 63) / 64), (unsigned)((a.m + 63) / 64));

@@ -189,21 +189,38 @@ def test_block_update_vs_oracle(key, n, k, m):
     assert np.linalg.norm(W.data() - ref) / np.linalg.norm(ref) < tol_for(key, n) * 10
 
 
-@pytest.mark.parametrize('key', ['s', 'd'])
-@pytest.mark.parametrize('M,N,m', [(300, 200, 7), (1000, 513, 33), (257, 1025, 128), (2000, 100, 70)])
+@pytest.mark.parametrize('key', KEYS)
+@pytest.mark.parametrize('M,N,m', [(300, 200, 7), (1000, 513, 33), (257, 1025, 128), (2000, 100, 70), (3001, 2200, 96)])
 def test_dense_apply_vs_oracle(key, M, N, m):
+    """Y = A X and Y = A^H X for row- and column-major A, every type: float on the 32x32x2 matrix-core kernels, double
+    and the complex types on dense_mfma16_kernel (real planes on the 16x16x4 shapes; conj(A) by the sign of the
+    im plane), ragged tile edges in all three dimensions."""
     from raleigh_amd.algebra.hip import Vectors, Matrix
     rng = np.random.default_rng(M + N)
     a, x, z = rnd((M, N), key, rng), rnd((m, N), key, rng), rnd((m, M), key, rng)
-    tol = 2e-4 if key == 's' else 1e-12
+    tol = 2e-4 if key in 'sc' else 1e-12
+    big = np.complex128 if key in 'cz' else np.float64
     for arr in (np.ascontiguousarray(a), np.asfortranarray(a)):
         A = Matrix(arr)
         y = Vectors(M, m, data_type=DT[key])
         A.apply(Vectors(x), y)
-        assert cases.rel(y.data(), ops.dense_apply(a.astype(np.float64), x.astype(np.float64))) < tol
+        assert cases.rel(y.data(), ops.dense_apply(a.astype(big), x.astype(big))) < tol
         w = Vectors(N, m, data_type=DT[key])
         A.apply(Vectors(z), w, transp=True)
-        assert cases.rel(w.data(), ops.dense_apply(a.astype(np.float64), z.astype(np.float64), True)) < tol
+        assert cases.rel(w.data(), ops.dense_apply(a.astype(big), z.astype(big), True)) < tol
+
+
+def test_dense_apply_valu_fallback_agrees(monkeypatch):
+    """The VALU kernel kept for unaligned layouts (RLH_DENSE_VALU=1 forces it) against the matrix-core kernel."""
+    from raleigh_amd.algebra.hip import Vectors, Matrix
+    rng = np.random.default_rng(12)
+    a, x = rnd((700, 450), 'z', rng), rnd((40, 450), 'z', rng)
+    A, X = Matrix(a), Vectors(x)
+    y1, y2 = Vectors(700, 40, data_type=np.complex128), Vectors(700, 40, data_type=np.complex128)
+    A.apply(X, y1)
+    monkeypatch.setenv('RLH_DENSE_VALU', '1')
+    A.apply(X, y2)
+    assert cases.rel(y1.data(), y2.data()) < 1e-13
 
 
 @pytest.mark.parametrize('m', [1, 5, 16, 32, 40])
