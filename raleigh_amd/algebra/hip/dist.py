@@ -210,6 +210,42 @@ class ShardedVectors(Vectors):
             out[:, r0:r1] = arr[:, :r1 - r0]
         return out[0] if i is not None else out
 
+    def gather_into(self, full):
+        """The whole block on EVERY rank's device: `full` (plain Vectors of the global dimension, as many vectors
+        selected) receives the selected vectors of all shards -- one all_gather on the kernels' stream, no host copy."""
+        c, L = self._comm, _lib.lib()
+        m = self.nvec()
+        if full.nvec() != m or full.dimension() != self._gdim or full.data_type() != self.data_type():
+            raise ValueError('gather_into needs a plain block of the global dimension and the same type')
+        if m < 1:
+            return
+        es = self._es
+        maxloc = int(np.max(np.diff(self._offsets)))
+        nloc = self._vdim
+        send = c.buffer(maxloc * m * es)
+        if nloc > 0:
+            _lib.check(L.rlh_copy(self._code, nloc, m, self.data_ptr(), self.ld(), send.data_ptr(), maxloc))
+        recv = c.buffer(c.size * maxloc * m * es)
+        if c.size > 1 or c.force:
+            c.dist.all_gather_into_tensor(recv, send, group=c.group)
+        else:
+            recv = send
+        for p in range(c.size):
+            r0, r1 = int(self._offsets[p]), int(self._offsets[p + 1])
+            if r1 > r0:
+                _lib.check(L.rlh_copy(self._code, r1 - r0, m, recv.data_ptr() + p * maxloc * m * es, maxloc,
+                                      full.data_ptr() + r0 * es, full.ld()))
+
+    def take_rows_of(self, full):
+        """This rank's rows of a plain block of the global dimension (the inverse of gather_into, local)."""
+        m = self.nvec()
+        if full.nvec() != m or full.dimension() != self._gdim:
+            raise ValueError('take_rows_of needs a plain block of the global dimension')
+        r0 = int(self._offsets[self._comm.rank])
+        if m > 0 and self._vdim > 0:
+            _lib.check(_lib.lib().rlh_copy(self._code, self._vdim, m, full.data_ptr() + r0 * self._es, full.ld(),
+                                           self.data_ptr(), self.ld()))
+
     def reduction_batch(self):
         return ShardedReductionBatch(self)
 

@@ -52,6 +52,7 @@ class SparseSymmetricSolver:
         self._lu = None
         self._device = bool(device)
         self._chain = None
+        self._work = None
 
     def analyse(self, a, sigma=0, b=None):
         a = scs.csc_matrix(a)
@@ -90,7 +91,7 @@ class SparseSymmetricSolver:
         return self._chain[dtype]
 
     def solve(self, b, x):
-        if self._device and not hasattr(b, 'comm'):
+        if self._device:
             try:
                 chain = self._device_chain(b.data_type())
             except _lib_error() as e:
@@ -101,7 +102,22 @@ class SparseSymmetricSolver:
                 warnings.warn('triangular factors could not be placed on the device (%s): solving on the host' % e)
                 self._device = False
             else:
-                chain.solve(b, x)
+                if hasattr(b, 'comm'):
+                    # row-sharded blocks (BASELINE config 5's layout): the factors are replicated, so every rank gathers the
+                    # block on ITS GPU (one all_gather on the kernels' stream), runs the chain there and keeps its rows --
+                    # no block leaves the devices (round 2 solved the gathered block on every rank's host cores)
+                    from .vectors import Vectors
+                    m = b.nvec()
+                    w = self._work
+                    if w is None or w[0].shape()[0] < m or w[0].data_type() != b.data_type():
+                        w = self._work = [Vectors(self._n, m, data_type=b.data_type()) for _ in range(2)]
+                    for v in w:
+                        v.select(m)
+                    b.gather_into(w[0])
+                    chain.solve(w[0], w[1])
+                    x.take_rows_of(w[1])
+                else:
+                    chain.solve(b, x)
                 return
         bh = b.data()
         x.fill(np.ascontiguousarray(self._lu.solve(np.ascontiguousarray(bh.T)).T, dtype=bh.dtype))

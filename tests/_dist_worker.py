@@ -146,6 +146,26 @@ def main():
     assert np.max(np.abs(lmd4[:4] - ana) / ana) < 1e-10
     assert fake_lib_calls().get('spmm_cheb_bf16', 0) > 10
 
+    # shift-invert on row-sharded vectors (BASELINE config 5's layout): the factors are replicated, the block is
+    # gathered on every rank's device (all_gather), solved by the triangular chain there, and no host solve runs
+    N5 = 9
+    A5 = sp.csr_matrix(lap3d(N5, N5, N5, 1.0, 1.01, 1.02).astype(np.complex128))
+    n5 = A5.shape[0]
+    S5 = sp.diags([np.full(n5 - 1, 0.3)], [1])
+    A5 = sp.csr_matrix(A5 + 1j * S5 - 1j * S5.T)
+    exact5 = np.linalg.eigvalsh(A5.toarray())
+    sigma5 = 0.5 * (exact5[20] + exact5[21])
+    calls_before = fake_lib_calls().get('rlh_sptrsv_solve_chain', 0)
+    np.random.seed(1)
+    lmd5, x5, status = partial_hevp(A5, sigma=sigma5, which=(3, 3), tol=1e-8, verb=-1,
+                                    vectors=lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm))
+    assert status == 0, status
+    want5 = np.sort(np.concatenate((exact5[18:21], exact5[21:24])))
+    assert np.max(np.abs(np.sort(lmd5) - want5)) < 1e-9 * np.abs(exact5).max()
+    assert fake_lib_calls().get('rlh_sptrsv_solve_chain', 0) > calls_before + 3      # the device chain did the solves
+    r5 = A5 @ x5 - x5 * lmd5
+    assert np.max(np.linalg.norm(r5, axis=0)) < 1e-6 * np.abs(exact5).max()
+
     # row-sharded dense operator and PCA (BASELINE config 4 layout): same answer as one rank
     from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix
     from raleigh_amd.algebra.hip import Vectors

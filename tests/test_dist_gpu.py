@@ -140,3 +140,24 @@ def test_sharded_pca_matches_single_gpu(comm):
     # the same subspace: the leading 30 components of one lie in the span of the other's 40
     c = np.linalg.svd(comps[:30] @ comps1.T, compute_uv=False)
     assert c.min() > 1 - 1e-3
+
+
+def test_sharded_shift_invert_stays_on_the_device(comm):
+    """BASELINE config 5's layout with the collectives forced: shift-invert on row-sharded complex blocks -- the block is
+    gathered on the device (all_gather on the kernels' stream), solved by the persistent triangular chain, and this
+    rank's rows are taken back: eigenvalues nearest an interior shift against the dense spectrum."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip.dist import ShardedVectors
+    N = 12
+    A = sp.csr_matrix(lap3d(N, N, N, 1.0, 1.01, 1.02).astype(np.complex128))
+    n = A.shape[0]
+    S = sp.diags([np.full(n - 1, 0.3)], [1])
+    A = sp.csr_matrix(A + 1j * S - 1j * S.T)
+    exact = np.linalg.eigvalsh(A.toarray())
+    sigma = 0.5 * (exact[40] + exact[41])
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(A, sigma=sigma, which=(4, 4), tol=1e-8, verb=-1,
+                                  vectors=lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm))
+    assert status == 0
+    want = np.sort(exact[37:45])
+    assert np.max(np.abs(np.sort(lmd) - want)) < 1e-10 * np.abs(exact).max()
