@@ -356,11 +356,14 @@ class ShardedSparseMatrix:
         new_idx = np.empty_like(cols)
         new_idx[own] = cols[own] - r0
         new_idx[~own] = n_own_pad + np.searchsorted(halo_cols, cols[~own])
-        ext = scs.csr_matrix((loc.data, new_idx.astype(np.int32), loc.indptr),
-                             shape=(r1 - r0, n_own_pad + halo_cols.size))
         self._n_own = r1 - r0
         self._n_halo = int(halo_cols.size)
         self._ld_halo = -(-self._n_halo // 8) * 8        # leading dimension of the halo block (16-byte rows of bfloat16)
+        # the column count is padded like the halo block (the extra columns are never referenced): the layout moves a
+        # window that would reach past the last column to END there, and only a column count that is a multiple of 8
+        # keeps such a window on the 16-byte pieces the bfloat16 staging needs
+        ext = scs.csr_matrix((loc.data, new_idx.astype(np.int32), loc.indptr),
+                             shape=(r1 - r0, n_own_pad + self._ld_halo))
         self._op = CsrOperator(ext, n_own=n_own_pad)
         self._nnz = nnz_global
         # receive plan: contiguous runs of halo rows per owner

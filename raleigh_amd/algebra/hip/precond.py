@@ -205,8 +205,16 @@ class ChebyshevPreconditioner:
         fused step reads u_k, u_{k-1}, x and writes u_{k+1} (`cheb_step`)."""
         m = x.nvec()
         if self._bf16 and self._low and not x.is_complex() and getattr(self._op, 'supports_bf16', lambda: False)():
-            self._apply_bf16(x, y, m)
-            return
+            try:
+                self._apply_bf16(x, y, m)
+                return
+            except _lib.RlhError as e:
+                # (a shard whose halo layout the 2-byte staging cannot take: the same polynomial on float32 work blocks)
+                if 'rlh_spmm_cheb_bf16' not in str(e):
+                    raise
+                import warnings
+                warnings.warn('bfloat16 work blocks refused by the operator (%s): float32 work blocks instead' % e)
+                self._bf16 = False
         nwork = 3 if self._low else 2
         # (capacity = shape()[0]: nvec() is the current selection and shrinks with the solver's block)
         if self._work is None or self._work[0].shape()[0] < m or self._work[0].dimension() != x.dimension():

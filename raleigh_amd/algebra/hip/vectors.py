@@ -528,12 +528,26 @@ class ReductionBatch:
         lefts = [lefts] if isinstance(lefts, Vectors) else list(lefts)
         if not 1 <= len(rights) <= 4 or not 1 <= len(lefts) <= 4:
             raise ValueError('1 to 4 blocks per side')
+        for v in rights + lefts:
+            self._check(v)
         self._reqs.append(('gram', rights, lefts))
         return len(self._reqs) - 1
 
     def dots(self, a, b):
+        self._check(a)
+        self._check(b)
+        if a.nvec() != b.nvec():
+            raise ValueError('Numbers of vectors differ')
         self._reqs.append(('dots', a, b))
         return len(self._reqs) - 1
+
+    def _check(self, v):
+        """Every block of a batch is read with the prototype's element type and (local) length."""
+        p = self._proto
+        if v.data_type() != p.data_type():
+            raise ValueError('Vectors data types differ')
+        if v._vdim != p._vdim:
+            raise ValueError('Vectors dimensions differ')
 
     def _buffer(self, nbytes):
         """Device buffer the results are written to (a communication buffer for row shards)."""

@@ -102,3 +102,21 @@ def test_combine2_host_logic(fake):
     assert np.allclose(A.data(), qxa.T @ x + qya.T @ y) and np.allclose(B.data(), qxb.T @ x + qyb.T @ y)
     with pytest.raises(ValueError):
         Vectors(x).combine2(qxa, qxb, Vectors(y), qya, qyb, B, A)
+
+
+def test_reduction_batch_rejects_foreign_blocks(fake):
+    """a batch reads every block with the prototype's type and length; anything else is refused."""
+    import numpy as np
+    import pytest
+    from raleigh_amd.algebra.hip import Vectors
+    x, y = Vectors(100, 3), Vectors(100, 2)
+    rb = x.reduction_batch()
+    rb.gram([x], [y])
+    with pytest.raises(ValueError):
+        rb.gram([x], [Vectors(90, 2)])
+    with pytest.raises(ValueError):
+        rb.gram([Vectors(100, 2, data_type=np.float32)], [x])
+    with pytest.raises(ValueError):
+        rb.dots(x, y)
+    with pytest.raises(ValueError):
+        rb.dots(x, Vectors(100, 3, data_type=np.complex128))
