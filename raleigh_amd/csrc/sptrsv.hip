@@ -228,7 +228,7 @@ struct TrsvOp {
 
 struct TrsvArgs {
   TrsvOp op[8];
-  int nops, total_units, ngroups, ppt, pl;
+  int nops, total_units, ngroups, ppt, pl, nap;
   int64_t n8;
   u32x4 *scratch;
   unsigned *ctrl;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void loadm_sc1(unsigned want, const u32x4 *p0, const 
 template <typename T>
 __device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T> cur, int64_t e, int64_t end, int64_t end_x, int sl,
                                            const int32_t *__restrict__ cols, const T *__restrict__ vals, const u32x4 *X, const u32x4 *R,
-                                           const int32_t *__restrict__ prev_pos, int ppt, int pp, Watch &watch) {
+                                           const int32_t *__restrict__ prev_pos, int ppt, int pp, int nap, Watch &watch) {
   constexpr int EPL = PieceOf<T>::EPL;
   while (e < end) {
     const int64_t en = e + 4 * (int64_t)sl;
@@ -380,7 +380,7 @@ __device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T>
       if ((want & 4u) && piece_ready<T>(x2.w)) want &= ~4u;
       if ((want & 8u) && piece_ready<T>(x3.w)) want &= ~8u;
       if (want == 0u || watch.expired()) break;
-      __builtin_amdgcn_s_sleep(1);
+      if (nap == 1) __builtin_amdgcn_s_sleep(1); else if (nap == 2) __builtin_amdgcn_s_sleep(2); else if (nap >= 4) __builtin_amdgcn_s_sleep(4);
     }
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
           asm volatile("" :: "v"(warm));
         }
         if (first && stamp) stamp[4] = wall_clock64();
-        if (work) accumulate<T>(acc, cur, e_first, end_all, end_x, sl, cols, vals, X, rhs, o.prev_pos, ppt, pp, watch);
+        if (work) accumulate<T>(acc, cur, e_first, end_all, end_x, sl, cols, vals, X, rhs, o.prev_pos, ppt, pp, a.nap, watch);
         if (first && stamp) stamp[5] = wall_clock64();
         first = false;
         // sum of the slices of a row: lanes PL apart inside a wave, then (rows wider than a wave) through the LDS
@@ -700,6 +700,7 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
   a.ctrl = (unsigned *)head->work;                            // (the control words open the allocation: zeroed per call)
   a.scratch = (u32x4 *)((char *)head->work + ctrl_bytes);
   a.err_host = c.async_err_d;
+  { const char *e = getenv("RLH_SPTRSV_NAP"); a.nap = (e && *e) ? atoi(e) : 1; }      // s_sleep between poll rounds (tunable)
   const char *trace_path = getenv("RLH_SPTRSV_TRACE");      // diagnostics: per-unit stamps of group 0 to this file (synchronises)
   if (trace_path && *trace_path) {
     RLH_HIP(hipMalloc((void **)&a.trace, (size_t)total_units * 128));
@@ -937,8 +938,9 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
       nlev = std::max(nlev, l + 1);
     }
   };
-  // what the transform is for is fewer levels: where it removes less than a quarter of them (a 7-point stencil: its chains
-  // along x are not what makes its factors deep) the extra entries cost more than the levels saved
+  // what the transform is for is fewer levels: where it removes less than a tenth of them the extra entries are not worth
+  // it (measured with the final kernel: ILUT factors of lap3d 100^3, 1 820 -> 1 417 levels, 2.74 -> 2.54 ms; lap3d 64^3 1.61 ->
+  // 1.30 ms; the FE and SuperLU factors, 5-7 times fewer levels, 3-4 times faster)
   {
     int32_t plain = 0;
     for (int64_t s = 0; s < n; ++s) {
@@ -952,7 +954,7 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     t->levels_plain = plain;
     const int B = block_limit();
     transform(B);
-    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.75 * (double)plain) transform(1);
+    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.9 * (double)plain) transform(1);
   }
   t->lev_off.assign((size_t)nlev + 1, 0);
   for (int64_t i = 0; i < n; ++i) t->lev_off[(size_t)level[(size_t)i] + 1]++;
