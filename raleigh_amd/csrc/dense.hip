@@ -13,6 +13,8 @@
 // LDS-tiled VALU kernel remains for unaligned layouts.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace rlh {
@@ -520,12 +522,15 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
   const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves: output rows x vectors
   const int64_t i0 = (int64_t)blockIdx.x * MR;
   const int v0 = blockIdx.y * BN;
-  Unit ra[UA], rb[UB];
+  Unit ra0[UA], rb0[UB], ra1[UA], rb1[UB];      // two register sets: the tile two K steps ahead is in flight
   auto zero_unit = [](Unit &u) {
 #pragma unroll
     for (int e = 0; e < EPU; ++e) u.e[e] = zero_of(T{});
   };
-  auto load_tiles = [&](int64_t k0) {
+  // (masking in a code path of its own: a per-element test of the loaded values in every step makes the compiler wait
+  // for the loads right where they are issued -- the first version of this kernel did, and ran at 42 % MFMA busy)
+  auto load_tiles_as = [&](int64_t k0, Unit (&ra)[UA], Unit (&rb)[UB], auto mask) {
+    constexpr bool MASK = decltype(mask)::value;
 #pragma unroll
     for (int q = 0; q < UA; ++q) {
       const int u = tid + q * 256;
@@ -534,19 +539,21 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
         int64_t i = i0 + r;
         i = i < a.ny ? i : a.ny - 1;                // clamped rows are computed but never stored
         const int64_t k = k0 + kq;
-        const int64_t kc = (k + EPU <= a.lda) ? k : 0;
+        const int64_t kc = (!MASK || k + EPU <= a.lda) ? k : 0;
         ra[q] = *reinterpret_cast<const Unit *>(A + i * a.lda + kc);
+        if constexpr (MASK) {
 #pragma unroll
-        for (int e = 0; e < EPU; ++e)
-          if (k + e >= a.nx) ra[q].e[e] = zero_of(T{});
+          for (int e = 0; e < EPU; ++e)
+            if (k + e >= a.nx) ra[q].e[e] = zero_of(T{});
+        }
       } else {                                      // EPU consecutive output rows at one k
         const int kk = u / (MR / EPU), rq = (u % (MR / EPU)) * EPU;
         int64_t i = i0 + rq;
         i = (i + EPU <= a.lda) ? i : 0;
         const int64_t k = k0 + kk;
-        const int64_t kc = k < a.nx ? k : 0;
+        const int64_t kc = (!MASK || k < a.nx) ? k : 0;
         ra[q] = *reinterpret_cast<const Unit *>(A + kc * a.lda + i);
-        if (k >= a.nx) zero_unit(ra[q]);
+        if constexpr (MASK) { if (k >= a.nx) zero_unit(ra[q]); }
       }
     }
 #pragma unroll
@@ -556,17 +563,23 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
       int vc = v0 + c;
       vc = vc < a.m ? vc : a.m - 1;
       const int64_t k = k0 + kq;
-      const int64_t kc = (k + EPU <= a.ldx) ? k : 0;
+      const int64_t kc = (!MASK || k + EPU <= a.ldx) ? k : 0;
       rb[q] = *reinterpret_cast<const Unit *>(X + (int64_t)vc * a.ldx + kc);
+      if constexpr (MASK) {
 #pragma unroll
-      for (int e = 0; e < EPU; ++e)
-        if (k + e >= a.nx) rb[q].e[e] = zero_of(T{});
+        for (int e = 0; e < EPU; ++e)
+          if (k + e >= a.nx) rb[q].e[e] = zero_of(T{});
+      }
     }
+  };
+  auto load_tiles = [&](int64_t k0, Unit (&ra)[UA], Unit (&rb)[UB]) {
+    if (k0 + BK > a.nx) load_tiles_as(k0, ra, rb, std::true_type{});       // (wave-uniform: the last K step only)
+    else load_tiles_as(k0, ra, rb, std::false_type{});
   };
   auto put = [](R *re, R *im, int at, const T &v) {          // one element into its plane(s)
     if constexpr (CPLX) { re[at] = v.re; im[at] = v.im; } else { re[at] = v; (void)im; }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const Unit (&ra)[UA], const Unit (&rb)[UB]) {
     R *are = ldsA[buf][0], *aim = ldsA[buf][NP - 1], *bre = ldsB[buf][0], *bim = ldsB[buf][NP - 1];
 #pragma unroll
     for (int q = 0; q < UA; ++q) {
@@ -600,12 +613,7 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
         for (int r = 0; r < 4; ++r) acc[pl][tv][tr][r] = (R)0;
   const int fi = lane & 15, fk = lane >> 4;
   const int row0 = wm * 16 * TR, vec0 = wn * 16 * TV;
-  int buf = 0;
-  if (a.nx > 0) { load_tiles(0); store_tiles(0); }
-  __syncthreads();
-  for (int64_t k0 = 0; k0 < a.nx; k0 += BK) {
-    const bool more = (k0 + BK < a.nx);
-    if (more) load_tiles(k0 + BK);
+  auto compute = [&](int buf) {
     const R *are = ldsA[buf][0], *aim = ldsA[buf][NP - 1], *bre = ldsB[buf][0], *bim = ldsB[buf][NP - 1];
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
@@ -633,9 +641,42 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
           }
         }
     }
-    if (more) store_tiles(buf ^ 1);
+  };
+  // K steps in pairs: at step t the LDS buffer t % 2 holds tile t, one register set holds tile t + 1 and the other
+  // receives tile t + 2 -- a global load has a whole step, its MFMAs and a barrier to arrive before it is needed
+  // (with one set the matrix cores of this kernel sat idle 57 % of the time behind s_waitcnt)
+  const int64_t nk = (a.nx + BK - 1) / BK;
+  constexpr bool DEEP = !(CPLX && sizeof(R) == 8);   // (complex double: two sets of four 16-byte units per tile spill)
+  if constexpr (DEEP) {
+    if (nk > 0) {
+      load_tiles(0, ra0, rb0);
+      store_tiles(0, ra0, rb0);
+      if (nk > 1) load_tiles(BK, ra1, rb1);
+    }
     __syncthreads();
-    buf ^= 1;
+    for (int64_t t = 0; t < nk; t += 2) {
+      if (t + 2 < nk) load_tiles((t + 2) * BK, ra0, rb0);
+      compute(0);
+      if (t + 1 < nk) store_tiles(1, ra1, rb1);
+      __syncthreads();
+      if (t + 1 >= nk) break;
+      if (t + 3 < nk) load_tiles((t + 3) * BK, ra1, rb1);
+      compute(1);
+      if (t + 2 < nk) store_tiles(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    int buf = 0;
+    if (nk > 0) { load_tiles(0, ra0, rb0); store_tiles(0, ra0, rb0); }
+    __syncthreads();
+    for (int64_t t = 0; t < nk; ++t) {
+      const bool more = t + 1 < nk;
+      if (more) load_tiles((t + 1) * BK, ra0, rb0);
+      if (buf == 0) compute(0); else compute(1);
+      if (more) store_tiles(buf ^ 1, ra0, rb0);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
   // D[v][i]: column (lane % 16) = output row; the vector is the D row: 4 (lane / 16) + reg for the f32 shape,
   // (lane / 16) + 4 reg for v_mfma_f64_16x16x4_f64 (its C/D map differs from every other shape's)
@@ -779,7 +820,12 @@ static int dense_impl(const DenseArgs &a) {
     if (ok) {
       // 64 rows x 64 vectors per workgroup (measured at 20000 x 20000 x 128 fp64: 33 TF against 27 TF for 64 x 128 tiles,
       // whose 313 workgroups leave the second round of the 256 CUs a quarter full, and 13 TF for the VALU kernel)
-      if constexpr (DT == RLH_D) return launch_mfma16<double, double, false, 2, 2>(a);
+      if constexpr (DT == RLH_D) {
+        const int tile = env_int_d("RLH_DENSE_D_TILE", 22);      // 22: 64 x 64, 24: 64 rows x 128 vectors, 42: 128 x 64 (tunable)
+        if (tile == 24 && a.m > 64) return launch_mfma16<double, double, false, 2, 4>(a);
+        if (tile == 42) return launch_mfma16<double, double, false, 4, 2>(a);
+        return launch_mfma16<double, double, false, 2, 2>(a);
+      }
       if constexpr (DT == RLH_Z) return launch_mfma16<c64, double, true, 2, 2>(a);
       if constexpr (DT == RLH_C) return launch_mfma16<c32, float, true, 2, 2>(a);
     }
