@@ -139,8 +139,6 @@ class LowerRankApproximation:
         dtype = right.data_type()
         if matrix.data_type() != dtype:
             raise ValueError('incompatible matrix type passed to update')
-        if numpy.dtype(dtype).kind == 'c':
-            raise ValueError('update: real data only')
         n1, ncol = matrix.shape()
         if ncol != right.dimension():
             raise ValueError('update: the new rows have %d columns, the components %d' % (ncol, right.dimension()))
@@ -163,17 +161,24 @@ class LowerRankApproximation:
             e1 = op.new_vectors(n1, 1)
             e1.fill(numpy.ones((1, n1), dtype=dtype))
             a1 = op.new_vectors(ncol, 1)
-            op.apply(e1, a1, transp=True)
+            op.apply(e1, a1, transp=True)                       # A1^H e1: the conjugate of the column sums
+            if numpy.dtype(dtype).kind == 'c':
+                a1.conjugate()
             mean_v = op.new_vectors(ncol, 1)
             mean_v.lincomb(n0 / n, self.__mean_v, 1.0 / n, a1)
             d = op.new_vectors(ncol, 1)
             d.lincomb(1.0, self.__mean_v, -1.0, mean_v)
-            c = d.dot(right)                                    # (k, 1): d = c^T R0 + d_perp
+            # the rows of the approximation are combinations of the v_i^H (A_s ~ sum_i l_i v_i^H): the row d = a0 - a is
+            # c V^H + d_perp with c_i = d v_i.  Held as conj(d) -- a vector like the v_i -- this is the usual projection:
+            # <conj(d), v_i> = conj(c_i), conj(d) - sum_i conj(c_i) v_i = conj(d_perp), which is also the new component
+            if numpy.dtype(dtype).kind == 'c':
+                d.conjugate()
+            c = d.dot(right)                                    # (k, 1): conj(c_i)
             d.add(right, -1.0, c)
             _project_out(d, right)
             e0 = left.new_vectors(1)
             e0.fill(numpy.ones((1, n0), dtype=dtype))
-            left.add(e0, 1.0, numpy.ascontiguousarray(c.T))     # L0 += e0 c
+            left.add(e0, 1.0, numpy.ascontiguousarray(numpy.conj(c).T))     # L0 += e0 c
             s = math.sqrt(float(numpy.abs(d.dots(d))[0]))
             if s > numpy.finfo(dtype).eps * max(sigma0, numpy.finfo(dtype).tiny):
                 d.scale(numpy.full((1,), s, dtype=dtype))
@@ -296,8 +301,9 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
     returns the new pair.  (The job of lra.py:213-227, 311-326 and `_lra_ortho`, done with two Gram
     matrices, two k x k eigenproblems and two block updates, whatever the conditioning of `right`.)
 
-    H = R R^H = U M U^H:  R = (U M^1/2) Q with orthonormal Q = M^-1/2 U^H R;  L R = (L U M^1/2) Q; then
-    (L U M^1/2)^H (L U M^1/2) = W D W^H gives L' = L U M^1/2 W, R' = W^H Q.  Directions of `right` with
+    The product is L V^H with V the vectors of `right` as columns (A_s ~ sum_i l_i v_i^H).  H = V^H V = U M U^H:
+    V1 = V U M^-1/2 is orthonormal and L V^H = (L U M^1/2) V1^H; then (L U M^1/2)^H (L U M^1/2) = W D W^H gives
+    L' = L U M^1/2 W, V' = V U M^-1/2 W (complex data included: no conjugations).  Directions of `right` with
     no weight (M below rounding) carry nothing and are dropped.  diagonal=False: only orthonormal `right`
     is asked for (what update() needs of the pair it starts from; the reference skips that step
     altogether unless told otherwise, lra.py:213)."""
@@ -307,7 +313,7 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
     dtype = right.data_type()
     wide = numpy.complex128 if numpy.dtype(dtype).kind == 'c' else numpy.float64
     small = 100 * numpy.finfo(dtype).eps
-    H = numpy.conj(right.dot(right)).astype(wide)
+    H = right.dot(right).astype(wide)                 # V^H V for right = the vectors v_i (the product is sum_i l_i v_i^H)
     H = (H + H.conj().T) / 2
     G = left.dot(left).astype(wide)
     G = (G + G.conj().T) / 2
@@ -328,7 +334,7 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
         # R = H^1/2 Q with H^(+-1/2) from the series in E = H - I (|E|^3 is below rounding here)
         E2 = E @ E
         B = numpy.eye(k) + E / 2 - E2 / 8
-        Bi = numpy.conj(numpy.eye(k) - E / 2 + 3 * E2 / 8)
+        Bi = numpy.eye(k) - E / 2 + 3 * E2 / 8
     else:
         mu, U = sla.eigh(H, driver='evd')
         keep = mu > numpy.finfo(dtype).eps * k * max(mu[-1], 0.0)
@@ -336,7 +342,7 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
             keep[-1] = True
         mu, U = mu[keep], U[:, keep]
         B = U * numpy.sqrt(mu)[None, :]
-        Bi = numpy.conj(U / numpy.sqrt(mu)[None, :])
+        Bi = U / numpy.sqrt(mu)[None, :]
     core = B.conj().T @ G @ B
     if numpy.dtype(dtype).itemsize // (2 if numpy.dtype(dtype).kind == 'c' else 1) == 4 and k >= 256:
         # single-precision data: the rotation is applied to single-precision blocks anyway, and the k x k
@@ -348,7 +354,7 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
     order = numpy.argsort(-lam)
     W = W[:, order]
     t_left = B @ W                                               # L' = L (U M^1/2 W)
-    t_right = Bi @ numpy.conj(W)                                 # R'_j = sum_i (W^H M^-1/2 U^H)[j, i] R_i
+    t_right = Bi @ W                                             # V' = V (U M^-1/2 W): L' V'^H = L V^H
     kk = t_left.shape[1]
     new_left = left.new_vectors(kk)
     new_right = right.new_vectors(kk)

@@ -81,3 +81,26 @@ def row_norm_rule_with_shift(m, n, dt):
     rows = lambda a: np.sqrt((np.abs(a) ** 2).sum(1))
     assert rows(D).max() <= 0.05 * 1.01 * rows(As).max()
     assert comps.shape[0] < min(m, n)
+
+
+def update_matches_one_shot(m0, m1, n, dt, k=8):
+    """pca(A1, have=pca(A0)) on complex data (missing item 6): the mean of ALL rows, orthonormal
+    components, and an error close to the optimal rank-k one of the stacked, centred data."""
+    from raleigh_amd.interfaces.pca import pca
+    A = data(m0 + m1, n, dt, rank=10, seed=7)
+    A0, A1 = A[:m0], A[m0:]
+    mean, trans, comps = pca(A0, npc=k)
+    mean, trans, comps = pca(A1, have=(mean, trans, comps))
+    single = dt == np.complex64
+    kk = comps.shape[0]
+    assert kk == k and trans.shape == (m0 + m1, kk) and comps.shape == (kk, n)
+    assert np.abs(mean.ravel() - A.mean(axis=0)).max() <= (2e-5 if single else 1e-12) * np.abs(A).max()
+    assert np.abs(comps.conj() @ comps.T - np.eye(kk)).max() <= (1e-4 if single else 1e-8)
+    As = centred(A.astype(np.complex128))
+    sg = np.linalg.svd(As, compute_uv=False)
+    best = np.sqrt(np.sum(sg[kk:] ** 2)) / np.sqrt(np.sum(sg ** 2))
+    ef = np.linalg.norm(As - trans @ comps.conj()) / np.linalg.norm(As)
+    assert ef <= 1.25 * best + (1e-5 if single else 1e-10), (ef, best)
+    G = trans.conj().T @ trans
+    d = np.real(np.diag(G))
+    assert np.abs(G - np.diag(d)).max() <= 1e-3 * d[0]

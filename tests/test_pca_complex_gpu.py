@@ -23,3 +23,8 @@ def test_pca_is_optimal(m, n, dt):
 @pytest.mark.parametrize('m,n,dt', [(400, 160, np.complex128), (160, 400, np.complex64)])
 def test_row_norm_rule_with_shift(m, n, dt):
     cases.row_norm_rule_with_shift(m, n, dt)
+
+
+@pytest.mark.parametrize('m0,m1,n,dt', [(300, 120, 90, np.complex128), (260, 60, 80, np.complex64)])
+def test_update_matches_one_shot(m0, m1, n, dt):
+    cases.update_matches_one_shot(m0, m1, n, dt)
