@@ -233,6 +233,7 @@ struct TrsvArgs {
   u32x4 *scratch;
   unsigned *ctrl;
   unsigned *err_host;                           // mapped host word (Context::async_err)
+  unsigned long long spin_ticks;                // 100 MHz wall-clock ticks a launch may spend before it gives up
   unsigned long long *trace;                    // diagnostics (RLH_SPTRSV_TRACE): 16 words per unit of group 0, or null
 };
 
@@ -280,14 +281,14 @@ __device__ __forceinline__ void load4_sc1(const u32x4 *p0, const u32x4 *p1, cons
 
 struct Watch {                                  // bounds every spin of one thread
   unsigned *ctrl, *err_host;
-  unsigned long long t0;
+  unsigned long long t0, limit;
   unsigned spins;
   bool dead;
   __device__ __forceinline__ bool expired() {  // call once per failed poll
     if (dead) return true;
     if ((++spins & 255u) == 0) {
       if (__hip_atomic_load(ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
-      else if ((unsigned long long)wall_clock64() - t0 > kSpinTicks) {
+      else if ((unsigned long long)wall_clock64() - t0 > limit) {
         __hip_atomic_store(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         dead = true;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void trsv_pipeline_kernel(const TrsvArgs a) {
   __shared__ __attribute__((aligned(16))) u32x4 s_red[4 * 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  Watch watch{a.ctrl, a.err_host, (unsigned long long)wall_clock64(), 0u, false};
+  Watch watch{a.ctrl, a.err_host, (unsigned long long)wall_clock64(), a.spin_ticks, 0u, false};
   const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & (kMaxXcd - 1);   // HW_REG_XCC_ID
   unsigned *const queues = a.ctrl + kCtrlHead + kMaxXcd * (a.ngroups + 1);
   for (int round = 0; round <= a.ngroups; ++round) {
@@ -700,6 +701,8 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
   a.ctrl = (unsigned *)head->work;                            // (the control words open the allocation: zeroed per call)
   a.scratch = (u32x4 *)((char *)head->work + ctrl_bytes);
   a.err_host = c.async_err_d;
+  a.spin_ticks = kSpinTicks;
+  { const char *e = getenv("RLH_SPTRSV_SPIN_TICKS"); if (e && *e && atoll(e) > 0) a.spin_ticks = (unsigned long long)atoll(e); }   // (tests)
   { const char *e = getenv("RLH_SPTRSV_NAP"); a.nap = (e && *e) ? atoi(e) : 1; }      // s_sleep between poll rounds (tunable)
   const char *trace_path = getenv("RLH_SPTRSV_TRACE");      // diagnostics: per-unit stamps of group 0 to this file (synchronises)
   if (trace_path && *trace_path) {
