@@ -183,6 +183,11 @@ typedef struct rlh_csr *rlh_csr_t;
 int rlh_csr_create(rlh_csr_t *h, int dtype, int64_t n_rows, int64_t n_cols,
                    const int64_t *indptr, const int32_t *indices,
                    const void *values);
+/* The Hermitian operator defined by the UPPER triangle of a square 0-based CSR matrix with sorted rows, as the
+ * reference hands it to mkl_?csrmm with the 'SUNF' / 'HUNF' descriptor (mkl_wrap.py:211-276: A = U + U^H - diag(U));
+ * entries below the diagonal, if stored, are ignored.  Single-GPU operator (n_own = n). */
+int rlh_csr_create_upper(rlh_csr_t *h, int dtype, int64_t n, const int64_t *indptr,
+                         const int32_t *indices, const void *values);
 int rlh_csr_destroy(rlh_csr_t h);
 int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
                  int64_t *device_bytes);

@@ -62,6 +62,7 @@ SIGNATURES = {
     'rlh_conj': [_int, _i64, _i64, _p, _i64],
     'rlh_gather_rows': [_int, _i64, _p, _i64, _p, _i64, _p, _i64],
     'rlh_csr_create': [ctypes.POINTER(_p), _int, _i64, _i64, _p, _p, _p],
+    'rlh_csr_create_upper': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p],
     'rlh_csr_destroy': [_p],
     'rlh_csr_info': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                      ctypes.POINTER(_i64)],

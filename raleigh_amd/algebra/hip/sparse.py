@@ -26,9 +26,11 @@ def full_from_upper(matrix):
 
 
 class CsrOperator:
-    """Device CSR (sliced-ELL) operator: y = A x for rows owned by this process."""
+    """Device CSR operator: y = A x for rows owned by this process.  upper=True: the Hermitian operator defined by
+    the upper triangle of `csr` (entries below the diagonal ignored), mirrored inside the library
+    (rlh_csr_create_upper) instead of by three SciPy passes on the host."""
 
-    def __init__(self, csr, n_own=None):
+    def __init__(self, csr, n_own=None, upper=False):
         csr = scs.csr_matrix(csr)
         csr.sort_indices()
         dt = csr.data.dtype.type
@@ -42,9 +44,18 @@ class CsrOperator:
         indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
         values = np.ascontiguousarray(csr.data)
         h = ctypes.c_void_p()
-        _lib.check(_lib.lib().rlh_csr_create(ctypes.byref(h), _lib.DTYPE_CODE[dt], csr.shape[0],
-                                             csr.shape[1], _lib.host_ptr(indptr),
-                                             _lib.host_ptr(indices), _lib.host_ptr(values)))
+        if upper:
+            if csr.shape[0] != csr.shape[1] or n_own is not None:
+                raise ValueError('an operator given by its upper triangle is square and unsharded')
+            _lib.check(_lib.lib().rlh_csr_create_upper(ctypes.byref(h), _lib.DTYPE_CODE[dt], csr.shape[0], _lib.host_ptr(indptr),
+                                                       _lib.host_ptr(indices), _lib.host_ptr(values)))
+            nnz, dummy = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(_lib.lib().rlh_csr_info(h, ctypes.byref(dummy), ctypes.byref(dummy), ctypes.byref(nnz), ctypes.byref(dummy)))
+            self._nnz = int(nnz.value)
+        else:
+            _lib.check(_lib.lib().rlh_csr_create(ctypes.byref(h), _lib.DTYPE_CODE[dt], csr.shape[0],
+                                                 csr.shape[1], _lib.host_ptr(indptr),
+                                                 _lib.host_ptr(indices), _lib.host_ptr(values)))
         self._h = h
 
     def __del__(self):
@@ -114,22 +125,26 @@ class Bf16Block:
 class SparseSymmetricMatrix:
 
     def __init__(self, matrix):
+        # the UPPER triangle of `matrix` defines the operator (sparse_mkl.py:16-40); the library mirrors it, so the
+        # matrix goes in as it comes (both triangles or one) and triu() is only taken if somebody asks for csr()
         try:
-            upper = matrix.csr()
+            self.__given = matrix.csr()
         except Exception:
-            upper = scs.triu(matrix, format='csr')
-            upper.sort_indices()
-        self.__csr = upper
-        self.__op = CsrOperator(full_from_upper(upper))
+            self.__given = scs.csr_matrix(matrix)
+        self.__upper = None
+        self.__op = CsrOperator(self.__given, upper=True)
 
     def size(self):
-        return self.__csr.shape[0]
+        return self.__given.shape[0]
 
     def data_type(self):
-        return self.__csr.data.dtype
+        return self.__given.data.dtype
 
     def csr(self):
-        return self.__csr
+        if self.__upper is None:
+            self.__upper = scs.triu(self.__given, format='csr')
+            self.__upper.sort_indices()
+        return self.__upper
 
     def nnz_full(self):
         return self.__op.nnz()

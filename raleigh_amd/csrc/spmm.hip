@@ -927,6 +927,49 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   return 0;
 }
 
+// The Hermitian operator defined by the UPPER triangle of a square CSR matrix (entries below the diagonal, if the caller
+// stores them, are ignored): A = U + U^H - diag(U), what mkl_?csrmm computes with the 'SUNF' / 'HUNF' descriptor the
+// reference passes (raleigh/algebra/mkl_wrap.py:211-276).  One counting pass and one fill pass over the entries on the
+// host (row i of the result = the mirrored entries (j, i), j < i, in ascending j, then the row's own upper entries:
+// sorted if the input rows are), then the ordinary rlh_csr_create.
+template <typename T> static inline T conj_of(T v) { return v; }
+template <> inline c32 conj_of(c32 v) { return c32{v.re, -v.im}; }
+template <> inline c64 conj_of(c64 v) { return c64{v.re, -v.im}; }
+
+template <typename T>
+static int csr_from_upper(rlh_csr_t *out, int dtype, int64_t n, const int64_t *indptr, const int32_t *indices, const T *values) {
+  std::vector<int64_t> rp((size_t)n + 1, 0), below((size_t)n, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t prev = -1;
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+      const int32_t j = indices[e];
+      RLH_REQUIRE(j >= 0 && j < n, "rlh_csr_create_upper: column index %d out of range in row %lld", j, (long long)i);
+      RLH_REQUIRE(j > prev, "rlh_csr_create_upper: the column indices of row %lld are not sorted", (long long)i);
+      prev = j;
+      if (j < i) continue;
+      ++rp[(size_t)i + 1];
+      if (j > i) { ++rp[(size_t)j + 1]; ++below[(size_t)j]; }
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
+  std::vector<int32_t> idx((size_t)rp[(size_t)n]);
+  std::vector<T> val((size_t)rp[(size_t)n]);
+  std::vector<int64_t> next_below(rp.begin(), rp.end() - 1);      // where the next mirrored entry of a row goes
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t w = rp[(size_t)i] + below[(size_t)i];                 // the row's own entries follow its mirrored ones
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+      const int32_t j = indices[e];
+      if (j < i) continue;
+      idx[(size_t)w] = j; val[(size_t)w] = values[e]; ++w;
+      if (j > i) {
+        const int64_t d = next_below[(size_t)j]++;
+        idx[(size_t)d] = (int32_t)i; val[(size_t)d] = conj_of(values[e]);
+      }
+    }
+  }
+  return rlh_csr_create(out, dtype, n, n, rp.data(), idx.data(), val.data());
+}
+
 }  // namespace rlh
 
 using namespace rlh;
@@ -985,6 +1028,25 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   if (rc) { rlh_csr_destroy(h); return rc; }
   *out = h;
   return 0;
+}
+
+int rlh_csr_create_upper(rlh_csr_t *out, int dtype, int64_t n, const int64_t *indptr, const int32_t *indices,
+                         const void *values) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(out != nullptr, "rlh_csr_create_upper: null handle pointer");
+  *out = nullptr;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_csr_create_upper: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && indptr != nullptr && indptr[0] == 0, "rlh_csr_create_upper: bad matrix");
+  for (int64_t r = 0; r < n; ++r)
+    RLH_REQUIRE(indptr[r + 1] >= indptr[r], "rlh_csr_create_upper: indptr decreases at row %lld", (long long)r);
+  RLH_REQUIRE(indptr[n] == 0 || (indices && values), "rlh_csr_create_upper: null indices/values");
+  switch (dtype) {
+    case RLH_S: return csr_from_upper<float>(out, dtype, n, indptr, indices, (const float *)values);
+    case RLH_D: return csr_from_upper<double>(out, dtype, n, indptr, indices, (const double *)values);
+    case RLH_C: return csr_from_upper<c32>(out, dtype, n, indptr, indices, (const c32 *)values);
+    case RLH_Z: return csr_from_upper<c64>(out, dtype, n, indptr, indices, (const c64 *)values);
+  }
+  return 1;
 }
 
 int rlh_csr_destroy(rlh_csr_t h) {

@@ -336,6 +336,21 @@ class FakeLib:
         ph._obj.value = h
         return 0
 
+    def rlh_csr_create_upper(self, ph, code, n, indptr, indices, values):
+        ip = _flat(indptr, np.int64, n + 1).copy()
+        nnz = int(ip[-1])
+        ix = _flat(indices, np.int32, nnz).copy()
+        va = _flat(values, _DT[code], nnz).copy()
+        if nnz and (ix.min() < 0 or ix.max() >= n):
+            return self._fail('rlh_csr_create_upper: column index out of range')
+        a = sp.csr_matrix((va, ix, ip), shape=(n, n))
+        u, s1 = sp.triu(a, format='csr'), sp.triu(a, k=1, format='csr')
+        h = self._next_handle
+        self._next_handle += 1
+        self._csr[h] = _Csr(sp.csr_matrix(u + s1.conj().T), code)
+        ph._obj.value = h
+        return 0
+
     # ---- ILUT (host-only entry points of the real library) and triangular chains (SciPy)
     def _real(self):
         import os
