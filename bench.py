@@ -387,16 +387,19 @@ def config_legs(L):
     # the ITERATION is timed at full size): block of 64, no preconditioner, two runs of different length
     from raleigh_amd.core.solver import Options
     ts = {}
-    for its in (4, 12):
+    for its in (2, 4, 12, 4, 12):                  # (a first short run takes the allocations; best of two for each length)
         np.random.seed(1)
         opt = Options()
         opt.max_iter, opt.block_size = its, 64
         lmd, x, status = partial_hevp(H, T=True, which=20, tol=1e-6, verb=-1, opt=opt)
         _lib.check(L.rlh_sync())
-        ts[its] = (float(partial_hevp.last['solve_time']), int(partial_hevp.last['iterations']))
+        t, n_it = float(partial_hevp.last['solve_time']), int(partial_hevp.last['iterations'])
+        if its not in ts or t < ts[its][0]:
+            ts[its] = (t, n_it)
         del lmd, x
     di = ts[12][1] - ts[4][1]
     c5['iteration_ms'] = round((ts[12][0] - ts[4][0]) / max(di, 1) * 1e3, 2)
+    c5['iteration_runs'] = {str(k): {'seconds': round(v[0], 4), 'iterations': v[1]} for k, v in ts.items() if k != 2}
     c5['iteration_what'] = ('block-JCG driver (raleigh_amd/core/solver.py), block of 64 complex128 vectors, n = 126^3, no preconditioner: '
                             'wall time per iteration from runs of %d and %d iterations' % (ts[4][1], ts[12][1]))
     out['config5'] = c5

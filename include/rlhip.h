@@ -200,6 +200,12 @@ int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
  * slot (windowed-layout analysis; 0 if it was not run).  RLH_SPMM_FORMAT=sell|well|wide in the
  * environment of rlh_csr_create overrides the choice. */
 int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per_slot);
+/* Stacked row blocks of the windowed layout (diagnostic): *stacks = workgroup-sized stacks of two 1024-row blocks whose
+ * column windows overlap (0: the layout was not built: no windowed layout, or stacking stages less than 10 % fewer
+ * elements); *staged_per_row / *staged_per_row_stacked = vector elements staged per row and vector without / with the
+ * stacks (3.42 / 2.42 for the 7-point stencil on 215^3).  rlh_spmm on the whole operator uses the stacks when they exist;
+ * RLH_SPMM_STACK=0 in the environment (create or call time) turns them off, =2 at create time builds them regardless. */
+int rlh_csr_stacks(rlh_csr_t h, int64_t *stacks, double *staged_per_row, double *staged_per_row_stacked);
 /* Columns [0, n_own) are read from X, columns [n_own, n_cols) from the halo block
  * H (row c - n_own), which holds the off-shard rows received from other ranks;
  * single GPU: n_own = n_cols, H = NULL. */

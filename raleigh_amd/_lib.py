@@ -67,6 +67,7 @@ SIGNATURES = {
     'rlh_csr_info': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                      ctypes.POINTER(_i64)],
     'rlh_csr_layout': [_p, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
+    'rlh_csr_stacks': [_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
     'rlh_spmm': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64],
     'rlh_spmm_cheb': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double, ctypes.c_double,
                       ctypes.c_double],

@@ -82,6 +82,13 @@ class CsrOperator:
         _lib.check(_lib.lib().rlh_csr_layout(self._h, ctypes.byref(lay), ctypes.byref(stored), ctypes.byref(ratio)))
         return ('sell', 'well', 'wide')[lay.value], int(stored.value), float(ratio.value)
 
+    def stacks(self):
+        """(stacks, staged elements per row and vector without / with them): the stacked row blocks of the windowed
+        layout (rlh_csr_stacks); 0 stacks when the layout was not built."""
+        n, a, b = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib().rlh_csr_stacks(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
+        return int(n.value), float(a.value), float(b.value)
+
     def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0, part=0):
         """part 0: all rows; 1: the rows that need no halo column; 2: the others (rlh_spmm_part)."""
         _lib.check(_lib.lib().rlh_spmm_part(self._h, part, m, x_ptr, ldx, self._n_own, halo_ptr, ldh, y_ptr, ldy))
@@ -169,6 +176,10 @@ class SparseSymmetricMatrix:
 
     def supports_bf16(self):
         return self.__op.data_type() == np.float32 and self.__op.layout()[0] == 'well'
+
+    def layout(self):
+        """Device layout of the operator and its stacked row blocks (diagnostics: CsrOperator.layout, .stacks)."""
+        return self.__op.layout() + self.__op.stacks()
 
 
 class Operator:

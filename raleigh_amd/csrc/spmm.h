@@ -2,6 +2,7 @@
 // the XCD-aware launch order used by both windowed layouts (spmm.hip, spmm_wide.inc).
 #pragma once
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -63,6 +64,20 @@ struct rlh_csr {
   int well_grid_part[2];
   int well_inbounds;       // every staging group lies inside [0, n_cols)
   int well_aligned;        // every staging group starts on a multiple of 8 columns
+  // the same layout over STACKS of row blocks (spmm.hip, "Stacked blocks"): a workgroup takes kStkR 1024-row blocks whose
+  // windows overlap (for a 3-D stencil two blocks one grid plane apart) and stages the union of their windows once
+  int64_t stk_blocks;      // stacks; 0: not built
+  WellMeta *stk_meta;      // device, per stack (eoff counts slots: member r's 8 slots start at eoff + 8 r)
+  int32_t *stk_member;     // device, kStkR per stack: the 1024-row blocks of the stack (-1: none)
+  int32_t *stk_gsrc;       // device
+  uint16_t *stk_idx;       // device
+  void *stk_vals;          // device
+  int32_t *stk_sched;      // device
+  int64_t stk_sched_len;
+  int stk_grid;
+  int stk_gmax;           // largest number of staging groups of a stack
+  double stk_staged;       // staged elements per row and vector (diagnostic; the unstacked layout's: well_staged)
+  double well_staged;
   // 256-row interleaved layout (any row length, any type)
   int64_t wide_blocks;     // 0: not built
   WideMeta *wide_meta;     // device
@@ -131,9 +146,9 @@ struct Win { int32_t start, len, off; };        // off: position of the window i
 // staging groups of `gs` columns that stay inside the column range where the matrix is wide enough (a
 // window at the far end is moved left instead of being padded past the last column).  Returns the
 // number of staged columns (a multiple of `round_groups` * gs); `ws` is left with at least one window.
-static inline int32_t find_windows(const int64_t *indptr, const int32_t *indices, int64_t r0, int64_t r1, int64_t nc,
-                                   int gap, int gs, int round_groups, std::vector<Win> &ws) {
-  std::vector<int32_t> cols(indices + indptr[r0], indices + indptr[r1]);
+// (`cols`: the referenced columns in any order, duplicates allowed; sorted in place)
+static inline int32_t find_windows_of(std::vector<int32_t> &cols, int64_t nc, int gap, int gs, int round_groups,
+                                      std::vector<Win> &ws) {
   std::sort(cols.begin(), cols.end());
   cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
   ws.clear();
@@ -168,6 +183,12 @@ static inline int32_t find_windows(const int64_t *indptr, const int32_t *indices
   }
   const int32_t unit = gs * round_groups;
   return (off + unit - 1) / unit * unit;
+}
+
+static inline int32_t find_windows(const int64_t *indptr, const int32_t *indices, int64_t r0, int64_t r1, int64_t nc,
+                                   int gap, int gs, int round_groups, std::vector<Win> &ws) {
+  std::vector<int32_t> cols(indices + indptr[r0], indices + indptr[r1]);
+  return find_windows_of(cols, nc, gap, gs, round_groups, ws);
 }
 
 // position of column c in the staged image (last window starting at or before c)
@@ -238,10 +259,75 @@ static inline void well_layout(const std::vector<int32_t> &order, int slots, std
   }
 }
 
-// Greedy grouping on the block-overlap graph: a group of `per_xcd` blocks is grown from the lowest
-// unscheduled block by repeatedly adding the unscheduled block that overlaps most with the group.
+// Launch groups on the block-overlap graph.  A group is the `per_xcd` units one XCD works on at the same time: what it
+// fetches over the fabric is the UNION of its units' windows, so a good group is a compact tile of the graph.
+//  * greedy: grown from the lowest unscheduled unit by repeatedly adding the unscheduled unit that overlaps most with
+//    the group -- on a 3-D stencil a column of units one plane apart (the heaviest edge every time): no re-read of the
+//    z planes inside the column, but every unit's y neighbours come from outside it;
+//  * tiles: the two id strides that carry the most overlap weight (for a stencil: one plane, one row block) span a
+//    lattice; a group is a w x (per_xcd / w) patch of it, topped up greedily where the lattice has holes.  For the 7-point
+//    stencil on 215^3 a 4 x 8 patch of two-plane stacks fetches 1.23 elements per row instead of the column's 1.45.
+// The candidate with the smallest total union is taken (RLH_SPMM_TILE=0: greedy only).  Speed only: any order is correct.
+// (`owner`: the schedule unit that owns row block c, when a unit is not simply its own row block)
+typedef std::vector<std::vector<std::pair<int32_t, int32_t>>> WellGraph;
+
+static inline void well_group_fill(const WellGraph &adj, std::vector<char> &done, std::vector<int64_t> &weight,
+                                   int64_t &seed, int per_xcd, std::vector<int32_t> &order,
+                                   const std::vector<int32_t> &first) {
+  const int64_t n = (int64_t)adj.size();
+  std::vector<int32_t> touched;
+  int members = 0;
+  auto add = [&](int32_t b) {
+    done[(size_t)b] = 1;
+    order.push_back(b);
+    ++members;
+    for (const auto &e : adj[(size_t)b])
+      if (!done[(size_t)e.first]) {
+        if (weight[(size_t)e.first] == 0) touched.push_back(e.first);
+        weight[(size_t)e.first] += e.second;
+      }
+  };
+  for (int32_t b : first)
+    if (members < per_xcd && !done[(size_t)b]) add(b);
+  while (members < per_xcd && (int64_t)order.size() < n) {
+    int32_t best = -1;
+    for (int32_t c : touched)
+      if (!done[(size_t)c] && (best < 0 || weight[(size_t)c] > weight[(size_t)best] ||
+                               (weight[(size_t)c] == weight[(size_t)best] && c < best)))
+        best = c;
+    if (best < 0) {
+      while (seed < n && done[(size_t)seed]) ++seed;
+      best = (int32_t)seed;
+    }
+    add(best);
+  }
+  for (int32_t c : touched) weight[(size_t)c] = 0;
+}
+
+// columns the groups of `order` fetch: per group the merged length of its units' windows
+static inline int64_t well_union_cost(const std::vector<std::vector<Win>> &wins, const std::vector<int32_t> &order,
+                                      int per_xcd) {
+  int64_t total = 0;
+  std::vector<std::pair<int32_t, int32_t>> iv;
+  for (size_t g = 0; g < order.size(); g += (size_t)per_xcd) {
+    iv.clear();
+    for (size_t k = g; k < order.size() && k < g + (size_t)per_xcd; ++k)
+      for (const Win &w : wins[(size_t)order[k]]) iv.push_back({w.start, w.start + w.len});
+    std::sort(iv.begin(), iv.end());
+    int32_t lo = 0, hi = -1;
+    for (const auto &p : iv) {
+      if (hi < 0) { lo = p.first; hi = p.second; }
+      else if (p.first <= hi) hi = std::max(hi, p.second);
+      else { total += hi - lo; lo = p.first; hi = p.second; }
+    }
+    if (hi >= 0) total += hi - lo;
+  }
+  return total;
+}
+
 static inline void well_schedule(const std::vector<std::vector<Win>> &wins, int64_t nblocks, int64_t n_rows,
-                                 int rows_per_block, int slots, std::vector<int32_t> &order) {
+                                 int rows_per_block, int slots, std::vector<int32_t> &order,
+                                 const std::vector<int32_t> *owner = nullptr) {
   const int xcds = 8;
   int per_xcd = slots / xcds;
   if (per_xcd < 1) per_xcd = 1;
@@ -251,47 +337,77 @@ static inline void well_schedule(const std::vector<std::vector<Win>> &wins, int6
     for (int64_t b = 0; b < nblocks; ++b) order.push_back((int32_t)b);
     return;
   }
-  // overlap graph: weight = rows of block c that block b stages (both directions)
-  std::vector<std::vector<std::pair<int32_t, int32_t>>> adj((size_t)nblocks);
+  // overlap graph: weight = rows of unit c that unit b stages (both directions)
+  WellGraph adj((size_t)nblocks);
   for (int64_t b = 0; b < nblocks; ++b)
     for (const auto &w : wins[b]) {
       int64_t lo = w.start, hi = (int64_t)w.start + w.len;
       if (hi > n_rows) hi = n_rows;                 // halo columns are not rows of this shard
       for (int64_t c = lo / rows_per_block; c * rows_per_block < hi; ++c) {
-        if (c == b) continue;
+        const int64_t u = owner ? (*owner)[(size_t)c] : c;
+        if (u == b || u < 0) continue;
         const int64_t ov = std::min<int64_t>(hi, (c + 1) * rows_per_block) - std::max<int64_t>(lo, c * rows_per_block);
         if (ov <= 0) continue;
-        adj[b].push_back({(int32_t)c, (int32_t)ov});
-        adj[c].push_back({(int32_t)b, (int32_t)ov});
+        adj[b].push_back({(int32_t)u, (int32_t)ov});
+        adj[u].push_back({(int32_t)b, (int32_t)ov});
       }
     }
   std::vector<char> done((size_t)nblocks, 0);
   std::vector<int64_t> weight((size_t)nblocks, 0);
   int64_t seed = 0;
-  while ((int64_t)order.size() < nblocks) {
-    std::vector<int32_t> touched;
-    int members = 0;
-    auto add = [&](int32_t b) {
-      done[b] = 1;
-      order.push_back(b);
-      ++members;
-      for (const auto &e : adj[b])
-        if (!done[e.first]) {
-          if (weight[e.first] == 0) touched.push_back(e.first);
-          weight[e.first] += e.second;
-        }
-    };
-    while (members < per_xcd && (int64_t)order.size() < nblocks) {
-      int32_t best = -1;
-      for (int32_t c : touched)
-        if (!done[c] && (best < 0 || weight[c] > weight[best] || (weight[c] == weight[best] && c < best))) best = c;
-      if (best < 0) {
-        while (seed < nblocks && done[seed]) ++seed;
-        best = (int32_t)seed;
-      }
-      add(best);
+  const std::vector<int32_t> none;
+  while ((int64_t)order.size() < nblocks) well_group_fill(adj, done, weight, seed, per_xcd, order, none);
+  if (env_int("RLH_SPMM_TILE", 1) == 0) return;
+  // the two strides that carry the most weight
+  std::vector<std::pair<int64_t, int64_t>> stride;          // (id difference, weight)
+  {
+    std::vector<std::pair<int64_t, int64_t>> all;
+    for (int64_t b = 0; b < nblocks; ++b)
+      for (const auto &e : adj[(size_t)b])
+        if (e.first > b) all.push_back({(int64_t)e.first - b, (int64_t)e.second});
+    std::sort(all.begin(), all.end());
+    for (size_t i = 0; i < all.size();) {
+      size_t k = i;
+      int64_t wsum = 0;
+      for (; k < all.size() && all[k].first == all[i].first; ++k) wsum += all[k].second;
+      stride.push_back({all[i].first, wsum});
+      i = k;
     }
-    for (int32_t c : touched) weight[c] = 0;
+    std::sort(stride.begin(), stride.end(), [](const std::pair<int64_t, int64_t> &a, const std::pair<int64_t, int64_t> &b) {
+      return a.second > b.second;
+    });
+  }
+  if (stride.size() < 2) return;
+  const int64_t d1 = stride[0].first, d2 = stride[1].first;
+  int64_t best_cost = well_union_cost(wins, order, per_xcd);
+  const bool verbose = env_int("RLH_SPMM_VERBOSE", 0) != 0;
+  if (verbose)
+    fprintf(stderr, "well_schedule: %lld units of %d rows-per-block, strides %lld (weight %lld) and %lld (%lld); greedy groups fetch %lld columns\n",
+            (long long)nblocks, rows_per_block, (long long)d1, (long long)stride[0].second, (long long)d2,
+            (long long)stride[1].second, (long long)best_cost);
+  for (int w = 2; w <= 8 && w < per_xcd; w *= 2) {
+    if (per_xcd % w) continue;
+    const int len = per_xcd / w;
+    std::vector<int32_t> cand, first;
+    cand.reserve((size_t)nblocks);
+    std::fill(done.begin(), done.end(), 0);
+    seed = 0;
+    while ((int64_t)cand.size() < nblocks) {
+      while (seed < nblocks && done[(size_t)seed]) ++seed;
+      first.clear();
+      for (int k = 0; k < len; ++k)
+        for (int i = 0; i < w; ++i) {
+          const int64_t u = seed + k * d1 + i * d2;
+          if (u < nblocks && !done[(size_t)u]) first.push_back((int32_t)u);
+        }
+      well_group_fill(adj, done, weight, seed, per_xcd, cand, first);
+    }
+    const int64_t cost = well_union_cost(wins, cand, per_xcd);
+    if (verbose) fprintf(stderr, "well_schedule: %d x %d tiles fetch %lld\n", w, len, (long long)cost);
+    if (cost < best_cost) {
+      best_cost = cost;
+      order.swap(cand);
+    }
   }
 }
 

@@ -439,6 +439,12 @@ class FakeLib:
         ctypes.cast(ratio, ctypes.POINTER(ctypes.c_double))[0] = 0.0
         return 0
 
+    def rlh_csr_stacks(self, h, stacks, a, b):
+        ctypes.cast(stacks, ctypes.POINTER(ctypes.c_int64))[0] = 0
+        ctypes.cast(a, ctypes.POINTER(ctypes.c_double))[0] = 0.0
+        ctypes.cast(b, ctypes.POINTER(ctypes.c_double))[0] = 0.0
+        return 0
+
     def _rows_of_part(self, c, part, n_own):
         """Row mask of rlh_spmm_part (granularity here: single rows; the library uses 1024-row blocks)."""
         nr = c.mat.shape[0]

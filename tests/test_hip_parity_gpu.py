@@ -580,6 +580,47 @@ def test_spmm_windowed_schedule_many_blocks(monkeypatch):
     assert cases.rel(Y.data(), ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < 1e-13
 
 
+@pytest.mark.parametrize('key', ['d', 's'])
+@pytest.mark.parametrize('m', [5, 12, 13, 32])
+@pytest.mark.parametrize('dma', ['1', '0'])
+def test_spmm_stacked_blocks(monkeypatch, key, m, dma):
+    """The stacked windowed layout (two overlapping 1024-row blocks per workgroup, rlh_csr_stacks) forced on matrices
+    that are too small to get it by default: 70 x 53 x 31 lap3d has 113 row blocks -- an odd number, so one stack has a
+    single member -- and 115 010 rows, so the last block is ragged; block sizes below 12 take the register-staged
+    kernel, the others the LDS-DMA ring (RLH_SPMM_STACK_DMA=0: register staging for all).  Against the oracle, and
+    bit for bit against the unstacked kernel on the same handle."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    monkeypatch.setenv('RLH_SPMM_STACK_DMA', dma)
+    A = sp.csr_matrix(lap3d(70, 53, 31, 1.0, 1.01, 1.02).astype(DT[key]))
+    n = A.shape[0]
+    rng = np.random.default_rng(40 + m)
+    x = rnd((m, n), key, rng)
+    op = SparseSymmetricMatrix(A)
+    lay = op.layout()
+    assert lay[0] == 'well' and lay[3] == 57 and lay[5] < 0.8 * lay[4]          # 57 stacks, a quarter less staged
+    X, Y = Vectors(x), Vectors(n, m, data_type=DT[key])
+    Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+    op.apply(X, Y)
+    y = Y.data()
+    assert cases.rel(y, ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < (2e-6 if key == 's' else 1e-13)
+    monkeypatch.setenv('RLH_SPMM_STACK', '0')                                   # (read per call: the plain blocks)
+    Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+    op.apply(X, Y)
+    assert np.array_equal(Y.data(), y)
+
+
+def test_spmm_stacks_only_where_they_pay(monkeypatch):
+    """Default policy: no stacks on a small stencil (fewer than four row blocks per CU); stacks of two planes on a large one."""
+    from raleigh_amd.algebra.hip import SparseSymmetricMatrix
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.delenv('RLH_SPMM_STACK', raising=False)
+    assert SparseSymmetricMatrix(lap3d(40, 40, 40, 1.0, 1.01, 1.02)).layout()[3] == 0
+    lay = SparseSymmetricMatrix(lap3d(110, 110, 110, 1.0, 1.01, 1.02)).layout()      # 1 300 row blocks
+    assert lay[0] == 'well' and lay[3] == 650 and lay[5] < 0.75 * lay[4]
+
+
 @pytest.mark.parametrize('key', KEYS)
 def test_fill_random_bit_exact(key):
     """rlh_fill_random against its oracle restatement: bit-exact, with row / vector offsets and
