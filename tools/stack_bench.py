@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--lap', type=int, default=0)
     ap.add_argument('--lap2d', type=int, default=0)
+    ap.add_argument('--herm', type=int, default=0, help='Hermitian lap3d + i skew of side N (BASELINE config 5; --dtype z or c)')
     ap.add_argument('--band', type=int, default=-1)
     ap.add_argument('--n', type=int, default=9_938_375)
     ap.add_argument('--m', type=int, default=32)
@@ -31,10 +32,13 @@ def main():
     from oracle.sparse import lap3d
     import scipy.sparse as sp
     L = _lib.lib()
-    dt = {'s': np.float32, 'd': np.float64}[args.dtype]
+    dt = {'s': np.float32, 'd': np.float64, 'c': np.complex64, 'z': np.complex128}[args.dtype]
     es = np.dtype(dt).itemsize
     t0 = time.time()
-    if args.lap:
+    if args.herm:
+        from raleigh_amd.synthetic import hermitian_lap3d_rows
+        A = hermitian_lap3d_rows(args.herm, args.herm, args.herm, 1.0, 1.01, 1.02, 0, args.herm ** 3)
+    elif args.lap:
         A = lap3d(args.lap, args.lap, args.lap, 1.0, 1.01, 1.02)
     elif args.lap2d:
         A = lap3d(args.lap2d, args.lap2d, 1, 1.0, 1.01, 1.02)
@@ -52,9 +56,13 @@ def main():
     X, Y = Vectors(n, m, data_type=dt), Vectors(n, m, data_type=dt)
     if n * m <= 40_000_000:
         x = rng.standard_normal((m, n)).astype(dt)
+        if args.dtype in 'cz':
+            x = x + 1j * rng.standard_normal((m, n)).astype(dt)
         X.fill(x)
     else:
         col = (2 * rng.random((1, n)) - 1).astype(dt)
+        if args.dtype in 'cz':
+            col = col + 1j * (2 * rng.random((1, n)) - 1).astype(dt)
         for j in range(m):
             X.select(1, j)
             X.fill(np.roll(col, 7 * j + 1, axis=1) * (1 + 0.01 * j))
@@ -76,7 +84,9 @@ def main():
 
     results = {}
     variants = [('blocks', {'RLH_SPMM_STACK': '0'})]
-    if stacks:
+    if stacks and args.dtype in 'cz':
+        variants += [('stacks, LDS-DMA', {'RLH_SPMM_STACK': '1'})]
+    elif stacks:
         variants += [('stacks, register staging', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '0'}),
                      ('stacks, LDS-DMA', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '1', 'RLH_SPMM_STACK_DBG': '0'})]
         if args.dbg:
@@ -111,7 +121,7 @@ def main():
         if name != 'blocks' and y.shape == base.shape:
             print('%-28s max |difference to blocks| = %.3e (max |y| = %.3e)' % (name, float(np.max(np.abs(y - base))), float(np.max(np.abs(base)))))
     if args.check and x is not None:
-        ref = (A @ x.T.astype(np.float64)).T
+        ref = (A @ x.T.astype(np.complex128 if args.dtype in 'cz' else np.float64)).T
         for name, y in results.items():
             print('%-28s relative error vs scipy = %.3e' % (name, float(np.linalg.norm(y - ref) / np.linalg.norm(ref))))
 
