@@ -76,6 +76,13 @@ struct rlh_csr {
   int64_t stk_sched_len;
   int stk_grid;
   int stk_gmax;           // largest number of staging groups of a stack
+  // the stacks without / with halo columns (rlh_spmm_part), as well_split keeps them for the blocks
+  std::vector<int32_t> stk_order, stk_maxcol;
+  int64_t stk_split_at;
+  int32_t *stk_sched_part[2];
+  int64_t stk_sched_part_len[2];
+  int stk_grid_part[2];
+  int stk_aligned;         // every staging group of the stacks starts on a multiple of 8 columns
   double stk_staged;       // staged elements per row and vector (diagnostic; the unstacked layout's: well_staged)
   double well_staged;
   // 256-row interleaved layout (any row length, any type)

@@ -682,7 +682,8 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
                                                               const uint16_t *__restrict__ idx,
                                                               const T *__restrict__ vals, int64_t n_rows,
                                                               const int32_t *__restrict__ sched, int64_t sched_len,
-                                                              const T *__restrict__ X, int64_t ldx,
+                                                              const T *__restrict__ X, int64_t ldx, int64_t n_own,
+                                                              const T *__restrict__ H, int64_t ldh,
                                                               T *__restrict__ Y, int64_t ldy, int m) {
   constexpr int WMAX = 8;
   constexpr int NB = StkRing<T>::NB, D = NB - 1;   // D vectors ahead
@@ -742,10 +743,11 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
     auto issue = [&](int j) {                      // the DMAs of vector j into slot j % NB
       const unsigned slot = (unsigned)(j & (NB - 1)) * (unsigned)SLOT;
       const T *src = X + (int64_t)j * ldx;
+      const T *hsrc = H ? H + (int64_t)j * ldh - n_own : src;   // halo row of column c: hsrc[c] (pieces never lie across n_own)
 #pragma unroll
       for (int i = 0; i < LD; ++i) {
         if (i >= mine || (DBG & 1)) break;
-        const T *g = src + scol[i];
+        const T *g = (scol[i] < n_own ? src : hsrc) + scol[i];
         unsigned dst = slot + (unsigned)(wave + 16 * i) * 1024u, keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
@@ -1011,10 +1013,15 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
 }
 
 template <typename T>
-static int launch_stack(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, T *Y, int64_t ldy) {
+static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
+                        int64_t ldh, T *Y, int64_t ldy, bool dma) {
   Context &c = ctx();
+  const int32_t *sched = part == 0 ? h->stk_sched : h->stk_sched_part[part - 1];
+  const int64_t sched_len = part == 0 ? h->stk_sched_len : h->stk_sched_part_len[part - 1];
+  const int grid = part == 0 ? h->stk_grid : h->stk_grid_part[part - 1];
+  if (grid == 0) return 0;
   constexpr bool cplx = std::is_same<T, c32>::value || std::is_same<T, c64>::value;
-  if (cplx || (env_int("RLH_SPMM_STACK_DMA", 1) != 0 && h->stk_gmax * 64 * (int)sizeof(T) <= StkRing<T>::SLOT)) {
+  if (dma) {
     constexpr int EPL = 16 / (int)sizeof(T);
     const int ld = (h->stk_gmax + 16 * EPL - 1) / (16 * EPL);          // 16-byte pieces per wave and vector
 #define RLH_STK_DMA(LD_, ...)                                                                                           \
@@ -1025,9 +1032,9 @@ static int launch_stack(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, T 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kStkLdsBytes));                         \
         attr_dma = true;                                                                                                \
       }                                                                                                                 \
-      hipLaunchKernelGGL((well_stack_dma_kernel<T, kStkR, LD_ __VA_ARGS__>), dim3((unsigned)h->stk_grid), dim3(1024),   \
+      hipLaunchKernelGGL((well_stack_dma_kernel<T, kStkR, LD_ __VA_ARGS__>), dim3((unsigned)grid), dim3(1024),          \
                          kStkLdsBytes, c.stream, h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                   \
-                         (const T *)h->stk_vals, h->n_rows, h->stk_sched, h->stk_sched_len, X, ldx, Y, ldy, (int)m);    \
+                         (const T *)h->stk_vals, h->n_rows, sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m);   \
     } while (0)
     const int dbg = env_int("RLH_SPMM_STACK_DBG", 0);
     if (dbg && ld == 3 && sizeof(T) == 8) {
@@ -1053,6 +1060,7 @@ static int launch_stack(const rlh_csr *h, int64_t m, const T *X, int64_t ldx, T 
     RLH_HIP(hipGetLastError());
     return 0;
   }
+  RLH_REQUIRE(part == 0 && H == nullptr, "rlh_spmm: the register-staged stack kernel takes the whole operator only");
   if constexpr (!cplx) {
     static bool attr = false;
     if (!attr) {
@@ -1077,6 +1085,28 @@ static int launch_well(const rlh_csr *h, int part, int64_t m, const T *X, int64_
 }
 
 static int well_split(rlh_csr *h, int64_t n_own);
+static int stack_split(rlh_csr *h, int64_t n_own);
+
+// Y = A X on the stacked layout where the handle has one and the call fits it: the whole operator on own columns with
+// either kernel; with a halo block, or on the interior / boundary part of the rows (rlh_spmm_part), the LDS-DMA kernel,
+// whose 16-byte pieces must then lie on one side of the own / halo boundary.
+template <typename T>
+static int stack_dispatch(rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
+                          T *Y, int64_t ldy, bool *done) {
+  constexpr bool cplx = std::is_same<T, c32>::value || std::is_same<T, c64>::value;
+  constexpr int EPL = 16 / (int)sizeof(T);
+  *done = false;
+  if (h->stk_blocks == 0 || env_int("RLH_SPMM_STACK", 1) == 0) return 0;
+  const bool dma = h->stk_gmax * 64 * (int)sizeof(T) <= StkRing<T>::SLOT && (cplx || env_int("RLH_SPMM_STACK_DMA", 1) != 0);
+  if (cplx && !dma) return 0;
+  if (part != 0 || H != nullptr) {
+    if (!dma || (H != nullptr && n_own != h->n_cols && !(h->stk_aligned && n_own % EPL == 0))) return 0;
+    if (part != 0)
+      if (int rc = stack_split(h, n_own)) return rc;
+  }
+  *done = true;
+  return launch_stack<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, dma);
+}
 
 template <int DT>
 static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ldx, int64_t n_own, const void *H_,
@@ -1088,9 +1118,11 @@ static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ld
   T *Y = (T *)Y_;
   ChebArgs<T> cargs{(const T *)B_, ldb, cy, cp, cb};
   const ChebArgs<T> *cheb = B_ ? &cargs : nullptr;
-  if constexpr (DType<DT>::cplx)                 // (a complex operator: the stacks beside its other layout)
-    if (h->stk_blocks > 0 && part == 0 && H == nullptr && cheb == nullptr && env_int("RLH_SPMM_STACK", 1) != 0)
-      return launch_stack<T>(h, m, X, ldx, Y, ldy);
+  if (cheb == nullptr && (DType<DT>::cplx || h->well_blocks > 0)) {     // (a complex operator: the stacks beside its other layout)
+    bool done = false;
+    const int rc = stack_dispatch<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, &done);
+    if (rc || done) return rc;
+  }
   if (h->wide_blocks > 0) {
     switch (DT) {
       case RLH_S: return wide_spmm_s(h, part, m, X_, ldx, n_own, H_, ldh, Y_, ldy, B_, ldb, cy, cp, cb);
@@ -1101,9 +1133,6 @@ static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ld
   }
   if constexpr (!DType<DT>::cplx) {
     if (h->well_blocks > 0) {
-      // the whole operator on own columns: the stacked layout where the matrix has one (overlapping row blocks)
-      if (h->stk_blocks > 0 && part == 0 && H == nullptr && cheb == nullptr && env_int("RLH_SPMM_STACK", 1) != 0)
-        return launch_stack<T>(h, m, X, ldx, Y, ldy);
       if (part != 0)
         if (int rc = well_split(h, n_own)) return rc;
       return launch_well<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
@@ -1216,6 +1245,28 @@ static int well_split(rlh_csr *h, int64_t n_own) {
 template <int DT>
 static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const void *values_,
                        const std::vector<std::vector<Win>> &wins, int64_t staged_unstacked);
+
+static int stack_split(rlh_csr *h, int64_t n_own) {       // (well_split for the stacks)
+  if (h->stk_split_at == n_own) return 0;
+  for (int k = 0; k < 2; ++k) {
+    if (h->stk_sched_part[k]) (void)hipFree(h->stk_sched_part[k]);
+    h->stk_sched_part[k] = nullptr;
+    h->stk_sched_part_len[k] = 0;
+    h->stk_grid_part[k] = 0;
+  }
+  std::vector<int32_t> part[2];
+  for (int32_t sb : h->stk_order) part[h->stk_maxcol[(size_t)sb] < n_own ? 0 : 1].push_back(sb);
+  for (int k = 0; k < 2; ++k) {
+    if (part[k].empty()) continue;
+    std::vector<int32_t> sched;
+    well_layout(part[k], ctx().num_cu, sched, h->stk_grid_part[k]);
+    h->stk_sched_part_len[k] = (int64_t)sched.size();
+    RLH_HIP(hipMalloc((void **)&h->stk_sched_part[k], sched.size() * sizeof(int32_t)));
+    RLH_HIP(hipMemcpy(h->stk_sched_part[k], sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  h->stk_split_at = n_own;
+  return 0;
+}
 
 // Host side of the 1024-row windowed layout.  Returns 0 with h->well_blocks == 0 when the matrix
 // does not qualify (a row longer than 8 entries, a block whose windows do not fit the LDS buffer,
@@ -1477,7 +1528,13 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   });
   for (int64_t g = 0; g < goff; ++g)
     if ((int64_t)gsrc[(size_t)g] + 64 > h->n_cols) return 0;            // 16-byte staging needs whole groups
-  std::vector<int32_t> order, sched;
+  h->stk_aligned = 1;
+  for (int64_t g = 0; g < goff; ++g)
+    if (gsrc[(size_t)g] & 7) h->stk_aligned = 0;
+  h->stk_maxcol.resize((size_t)nst);
+  for (int64_t sb = 0; sb < nst; ++sb) h->stk_maxcol[(size_t)sb] = swins[(size_t)sb].back().start + swins[(size_t)sb].back().len - 1;
+  std::vector<int32_t> &order = h->stk_order;
+  std::vector<int32_t> sched;
   well_schedule(swins, nst, n, kWellRows, ctx().num_cu, order, &owner);
   well_layout(order, ctx().num_cu, sched, h->stk_grid);
   h->stk_sched_len = (int64_t)sched.size();
@@ -1570,6 +1627,8 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->well_blocks = 0; h->well_meta = nullptr; h->well_gsrc = nullptr; h->well_idx = nullptr; h->well_vals = nullptr;
   h->well_ratio = 0.0; h->well_sched = nullptr; h->well_sched_len = 0; h->well_grid = 0; h->well_inbounds = 0; h->well_aligned = 0;
   h->stk_blocks = 0; h->stk_meta = nullptr; h->stk_member = nullptr; h->stk_gsrc = nullptr; h->stk_idx = nullptr;
+  h->stk_split_at = -1; h->stk_sched_part[0] = h->stk_sched_part[1] = nullptr; h->stk_sched_part_len[0] = h->stk_sched_part_len[1] = 0;
+  h->stk_grid_part[0] = h->stk_grid_part[1] = 0; h->stk_aligned = 0; h->stk_gmax = 0;
   h->stk_vals = nullptr; h->stk_sched = nullptr; h->stk_sched_len = 0; h->stk_grid = 0; h->stk_staged = 0.0; h->well_staged = 0.0;
   h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
   h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
@@ -1642,6 +1701,8 @@ int rlh_csr_destroy(rlh_csr_t h) {
     if (h->stk_idx) (void)hipFree(h->stk_idx);
     if (h->stk_vals) (void)hipFree(h->stk_vals);
     if (h->stk_sched) (void)hipFree(h->stk_sched);
+    for (int k = 0; k < 2; ++k)
+      if (h->stk_sched_part[k]) (void)hipFree(h->stk_sched_part[k]);
     for (int k = 0; k < 2; ++k)
       if (h->well_sched_part[k]) (void)hipFree(h->well_sched_part[k]);
     wide_destroy(h);

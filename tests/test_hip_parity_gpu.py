@@ -617,6 +617,58 @@ def test_spmm_stacked_blocks(monkeypatch, key, m, dma):
         assert cases.rel(Y.data(), y) < tol
 
 
+@pytest.mark.parametrize('key', ['d', 's', 'z'])
+def test_spmm_stacked_blocks_with_halo(monkeypatch, key):
+    """The stacked layout on a row shard (rlh_spmm_part): the LDS-DMA kernel fetches the pieces right of the own / halo
+    boundary from the halo block; part 1 (stacks without halo columns) must not touch it -- NaNs here -- and parts 1 + 2,
+    as well as the whole shard in one call, give the product.  Grid planes of exactly three row blocks, so that the
+    stacks' images fit a ring slot for every type."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    A = _sym(lap3d(64, 48, 30, 1.0, 1.01, 1.02), key)
+    n = A.shape[0]
+    r0, r1 = 3072 * 4 + 100, 3072 * 26 + 777
+    loc = A[r0:r1]
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    n_own_pad = -(-(r1 - r0) // 8) * 8
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(r1 - r0)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    ncols = -(-(n_own_pad + len(halo)) // 8) * 8
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr), shape=(r1 - r0, ncols))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    assert op.stacks()[0] > 0
+    rng = np.random.default_rng(13)
+    m = 9
+    x = rnd((m, n), key, rng)
+    xo = np.zeros((m, n_own_pad), dtype=DT[key])
+    xo[:, :r1 - r0] = x[:, r0:r1]
+    hg = np.zeros((m, ncols - n_own_pad), dtype=DT[key])
+    hg[:, :len(halo)] = x[:, halo]
+    X, Hgood = Vectors(xo), Vectors(hg)
+    Hbad = Vectors(np.full((m, ncols - n_own_pad), np.nan, dtype=DT[key]))
+    Y = Vectors(r1 - r0, m, data_type=DT[key])
+    Y.fill(np.full((m, r1 - r0), 777, dtype=DT[key]))
+    ref = (A @ x.T).T[:, r0:r1]
+    tol = 3e-6 if key == 's' else 1e-13
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hbad.data_ptr(), Hbad.ld(), part=1)
+    y1 = Y.data()
+    done = y1[0] != 777
+    assert 0.5 < done.mean() < 1.0 and np.all(np.isfinite(y1[:, done])) and cases.rel(y1[:, done], ref[:, done]) < tol
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hgood.data_ptr(), Hgood.ld(), part=2)
+    y12 = Y.data()
+    assert cases.rel(y12, ref) < tol
+    Y.fill(np.full((m, r1 - r0), 777, dtype=DT[key]))
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hgood.data_ptr(), Hgood.ld(), part=0)
+    assert np.array_equal(Y.data(), y12)
+    monkeypatch.setenv('RLH_SPMM_STACK', '0')               # the other layout of the same handle
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld(), Hgood.data_ptr(), Hgood.ld(), part=0)
+    assert cases.rel(Y.data(), y12) < tol
+
+
 def test_spmm_stacks_only_where_they_pay(monkeypatch):
     """Default policy: no stacks on a small stencil (fewer than four row blocks per CU); stacks of two planes on a large one."""
     from raleigh_amd.algebra.hip import SparseSymmetricMatrix
