@@ -76,8 +76,6 @@ class LowerRankApproximation:
         (lra.py:109-149 -> partial_svd.py:52-133)."""
         if norm not in ('f', 's', 'm'):
             raise ValueError('norm %s is not supported' % repr(norm))
-        if norm != 'f' and _deflate is not None:
-            raise ValueError("only the Frobenius norm ('f') is available for an update")
         if opt is None:
             opt = Options()
         m, n = matrix.shape()
@@ -100,6 +98,11 @@ class LowerRankApproximation:
             else:       # 's': sigma_k against sigma_0, 'm': the largest row of the remainder (truncated_svd.py:206-283)
                 from .truncated_svd import _TruncationStopping
                 opt.stopping_criteria = _TruncationStopping(matrix, psvd, tol, norm, max_rank, verb, shift=shift)
+                if norm == 'm' and _deflate is not None:
+                    # an update: the rows of E = A_s - C R0 (R0 orthonormal) are those of A_s less their coefficients
+                    rows = opt.stopping_criteria.rows
+                    C = _deflate[1]
+                    rows.err2 = numpy.maximum(rows.err2 - numpy.abs(C.dots(C, transp=True)).astype(numpy.float64), 0.0)
         try:
             psvd.compute(opt, rank, refine)
         finally:
@@ -131,8 +134,8 @@ class LowerRankApproximation:
         tol = self.__tol if tol is None else tol
         norm = self.__norm if norm is None else norm
         svtol = self.__svtol if svtol is None else svtol
-        if norm != 'f':
-            raise ValueError("only the Frobenius norm ('f') stopping criterion is available")
+        if norm not in ('f', 's', 'm'):
+            raise ValueError('norm %s is not supported' % repr(norm))
         if tol == 0.0 and rank < 1:
             rank = self.__rank
         left, right = self.__left_v, self.__right_v
@@ -196,11 +199,20 @@ class LowerRankApproximation:
         PartialSVD(matrix, shift=True, mean=mean_v).op_svd().forward(right, C)
         rest2 = max(frob2 - float(numpy.sum(numpy.abs(C.dots(C)))), 0.0)     # |E|_F^2
 
-        if rest2 <= (numpy.finfo(dtype).eps * 16) ** 2 * frob2 or (rank < 0 and math.sqrt(rest2) <= tol * math.sqrt(frob2) / 4):
+        # what the inner decomposition of the new rows is stopped against (lra.py:262-270): the Frobenius norm of the
+        # shifted new rows, their largest row, or the leading singular value of the approximation in hand
+        scale = math.sqrt(frob2)
+        if rank < 0 and norm == 'm':
+            from .truncated_svd import _RowErrors
+            scale = _RowErrors(matrix, PartialSVD(matrix, shift=True, mean=mean_v), shift=True).initial
+        elif rank < 0 and norm == 's':
+            scale = sigma0
+        if rest2 <= (numpy.finfo(dtype).eps * 16) ** 2 * frob2 or \
+                (rank < 0 and norm == 'f' and math.sqrt(rest2) <= tol * math.sqrt(frob2) / 4):
             pass        # the components in hand already describe the new rows: nothing to add
         elif rank < 0:
             urank = max_rank * n1 // n if max_rank > 0 else -1
-            lra.compute(matrix, opt, tol=-tol * math.sqrt(frob2), max_rank=urank, svtol=svtol, shift=True,
+            lra.compute(matrix, opt, tol=-tol * scale, norm=norm, max_rank=urank, svtol=svtol, shift=True,
                         verb=verb, _mean=mean_v, _deflate=(right, C), _frob2=rest2)
         else:
             urank = max(1, rank * n1 // n)
@@ -225,14 +237,40 @@ class LowerRankApproximation:
 
         ncomp = right.nvec()
         if rank < 0:
+            # trailing components are dropped while what they carry stays below a quarter of the tolerance, in the norm
+            # asked for (lra.py:313-352; for 's' the reference indexes the singular values of the OLD approximation with
+            # the new number of components and fails -- here: those of the new one)
             r = numpy.abs(left.dots(left))
-            eps = math.sqrt(float(numpy.sum(r))) * tol / 4
-            tail, drop = 0.0, 0
-            while drop + 1 < ncomp:
-                tail += float(r[ncomp - 1 - drop])
-                if math.sqrt(tail) > eps:
-                    break
-                drop += 1
+            drop = 0
+            if norm == 'f':
+                eps = math.sqrt(float(numpy.sum(r))) * tol / 4
+                tail = 0.0
+                while drop + 1 < ncomp:
+                    tail += float(r[ncomp - 1 - drop])
+                    if math.sqrt(tail) > eps:
+                        break
+                    drop += 1
+            elif norm == 's':
+                eps = math.sqrt(float(r[0])) * tol / 4
+                while drop + 1 < ncomp and math.sqrt(float(r[ncomp - 1 - drop])) <= eps:
+                    drop += 1
+            else:
+                # the largest row of the discarded columns: monotone in their number, so bisect on it (one pass over the
+                # trailing columns per probe instead of one per column)
+                def largest_row(t):
+                    left.select(t, ncomp - t)
+                    v = math.sqrt(float(numpy.amax(numpy.abs(left.dots(left, transp=True)))))
+                    left.select(ncomp)
+                    return v
+                eps = largest_row(ncomp) * tol / 4
+                lo, hi = 0, ncomp - 1                       # largest_row(lo) <= eps holds, hi is the most we may drop
+                while lo < hi:
+                    mid = (lo + hi + 1) // 2
+                    if largest_row(mid) <= eps:
+                        lo = mid
+                    else:
+                        hi = mid - 1
+                drop = lo
             if drop > 0 and verb > 0:
                 print('discarding %d components out of %d' % (drop, ncomp))
             ncomp -= drop

@@ -6,11 +6,11 @@ lra.py:109-149, partial_svd.py:52-133, 238-301), restated for this repository's
 Vectors / Matrix: the hot loop is the pair of dense products of ``_OperatorSVD.apply``
 (rlh_dense_apply, MFMA for fp32) plus the usual block algebra.
 
-Supported: a fixed number of components (``npc``) and the Frobenius-norm tolerance
-(``tol`` with ``norm='f'``), with the mean shift; samples >= features or the transposed
-case; the update of an existing approximation with new samples (``have``) and incremental
-PCA (``batch_size``), see lra.py (Frobenius norm only); the 's' and 'm' norms for the one-shot
-case.  Out of scope: interactive stopping.
+Supported: a fixed number of components (``npc``) or a tolerance (``tol``) on the Frobenius
+norm ('f'), the largest singular value ('s') or the largest row ('m') of the remainder, with
+the mean shift; samples >= features or the transposed case; the update of an existing
+approximation with new samples (``have``) and incremental PCA (``batch_size``), see lra.py.
+Out of scope: interactive stopping.
 """
 
 import math
@@ -289,8 +289,6 @@ def pca(A, npc=-1, tol=0, have=None, batch_size=None, verb=0, arch='hip', norm='
     from .lra import LowerRankApproximation, _as_matrix
     if norm not in ('f', 's', 'm'):
         raise ValueError('norm %s is not supported' % repr(norm))
-    if norm != 'f' and (have is not None or batch_size is not None):
-        raise ValueError("only the Frobenius norm ('f') is available for an update / incremental PCA")
     if opt is None:
         opt = Options()
     lra = LowerRankApproximation(have)

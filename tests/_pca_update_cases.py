@@ -123,7 +123,38 @@ def refusals():
     with pytest.raises(RuntimeError):
         LowerRankApproximation().update(AMatrix(A[300:]))                         # nothing to update
     with pytest.raises(ValueError):
-        pca(A, batch_size=100, npc=5, norm='s')
+        pca(A, batch_size=100, npc=5, norm='x')
+
+
+def update_with_other_norms(golden_dir):
+    """pca(have=...) stopped by the largest row ('m': against the reference's own result) and by the largest singular
+    value ('s': the reference fails there with an IndexError -- lra.py:342 indexes the singular values of the OLD
+    approximation with the new number of components -- so the property itself is checked) of the remainder; then the
+    incremental variant under 'm'."""
+    from raleigh_amd.interfaces import pca, pca_error
+    k = known(golden_dir)['pca_600x400_update_tol_m']
+    assert 'failed' in known(golden_dir)['pca_600x400_update_tol_s']
+    A = data_600x400()
+    A0, A1 = A[:480], A[480:]
+    As = (A - A.mean(axis=0)).astype(np.float64)
+    mean, trans, comps = pca(A0, tol=0.05, norm='m')
+    assert abs(comps.shape[0] - k['ncomp_before']) <= 0.1 * k['ncomp_before']
+    mean, trans, comps = pca(A1, have=(mean, trans, comps), tol=0.05, norm='m')
+    check_shape_of_result(A, mean, trans, comps)
+    em, ef = pca_error(A, mean, trans, comps)
+    assert em <= 0.05 * 1.05 and em <= 1.5 * k['em'] and ef <= 1.2 * k['ef']
+    assert abs(comps.shape[0] - k['ncomp']) <= 0.15 * k['ncomp']
+    sv = np.linalg.norm(trans, axis=0)[:10]
+    assert np.max(np.abs(sv - np.array(k['sigma'])) / k['sigma'][0]) < 2e-3
+    mean, trans, comps = pca(A0, tol=0.05, norm='s')
+    mean, trans, comps = pca(A1, have=(mean, trans, comps), tol=0.05, norm='s')
+    check_shape_of_result(A, mean, trans, comps)
+    D = (trans @ comps).astype(np.float64) - As
+    assert np.linalg.norm(D, 2) <= 0.05 * np.linalg.norm(As, 2) * 1.3     # (two truncations of tol each, in quadrature)
+    mean, trans, comps = pca(A, batch_size=200, tol=0.05, norm='m')
+    check_shape_of_result(A, mean, trans, comps)
+    em, ef = pca_error(A, mean, trans, comps)
+    assert em <= 0.05 * 1.5
 
 
 def fewer_samples_than_features():

@@ -299,6 +299,16 @@ def pca_update_known_answers():
     record('pca_600x400_update_tol', *pca(A1, have=(mean, trans, comps)))
     mean, trans, comps = pca(A0, npc=30)
     record('pca_600x400_update_npc30', *pca(A1, have=(mean, trans, comps)))
+    # the other two norms of the stopping criterion (lra.py:262-270, 313-352); 's' may fail in the reference (its final
+    # truncation indexes the singular values of the OLD approximation with the new number of components): recorded if it runs
+    for nm in ('m', 's'):
+        try:
+            mean, trans, comps = pca(A0, tol=0.05, norm=nm)
+            k0 = comps.shape[0]
+            record('pca_600x400_update_tol_' + nm, *pca(A1, have=(mean, trans, comps), tol=0.05, norm=nm))
+            res['pca_600x400_update_tol_' + nm]['ncomp_before'] = int(k0)
+        except Exception as e:      # pragma: no cover
+            res['pca_600x400_update_tol_' + nm] = {'failed': repr(e)}
     record('pca_600x400_incremental_tol', *pca(A, batch_size=200, tol=0.05))
     record('pca_600x400_incremental_npc30', *pca(A, batch_size=200, npc=30))
     return res

@@ -43,6 +43,10 @@ def test_other_norms():
     cases.other_norms()
 
 
+def test_update_with_other_norms(golden_dir):
+    cases.update_with_other_norms(golden_dir)
+
+
 def test_fp32_batch_with_as_many_components_as_rows():
     """200 x 400 fp32 rows, tolerance mode: the block solver hands the whole problem to the dense
     Rayleigh-Ritz step in the complement (solver.py:502-585).  With the random basis orthonormalised in

@@ -38,6 +38,10 @@ def test_other_norms():
     cases.other_norms()
 
 
+def test_update_with_other_norms(golden_dir):
+    cases.update_with_other_norms(golden_dir)
+
+
 def test_reference_doctests_incremental_and_update():
     """generate(3000, 2000, 1000): pca(A, batch_size=1000, tol=0.05) -> 'max 2-norm 2e-02, Frobenius norm 4e-02';
     pca(A[:2400], tol=0.05) then pca(A[2400:], have=...) -> '2e-02, 5e-02' for all rows (pca.py:108-133).
