@@ -23,6 +23,7 @@ update(), with the existing approximation A0 - e0 a0 ~ L0 R0 (n0 rows) and n1 ne
 """
 
 import math
+import os
 
 import numpy
 import scipy.linalg as sla
@@ -30,6 +31,34 @@ import scipy.linalg as sla
 from ..algebra.dense_matrix import AMatrix
 from ..core.solver import Options
 from .pca import PartialSVD, _SingularValueCriteria, _FrobeniusStopping, _project_out
+
+
+_DEVICE_EIGH_MIN = 768
+
+
+def _eigh(a, single=False):
+    """Eigenpairs (ascending) of a Hermitian k x k matrix.  The k x k problems are the cost of an update once k reaches
+    the thousands (k = 1400: 0.36-0.41 s per call with LAPACK on the GPU box's host cores, against 0.05 s for all the
+    dense products of the update), so from k = 768 on the matrix goes to the vendor's dense eigensolver on the GPU
+    through PyTorch (torch.linalg.eigh: 0.033 s at k = 1400, 0.08 s at 2800 -- what the reference hands to LAPACK,
+    raleigh/interfaces/lra.py:216-222, on the device the data lives on).  RLH_DEVICE_EIGH=0, or no PyTorch with a GPU:
+    LAPACK on the host, as before -- in single precision if `single` (single-precision data, k >= 256: the rotation is
+    applied to single-precision blocks anyway, and it halves the host time; on the device double costs the same as
+    single and the vendor's single-precision solver orders close eigenvalues less reliably)."""
+    k = a.shape[0]
+    if k >= _DEVICE_EIGH_MIN and os.environ.get('RLH_DEVICE_EIGH', '1') != '0':
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from .. import _lib
+                dev = torch.device('cuda', _lib.device() or 0)
+                lam, w = torch.linalg.eigh(torch.from_numpy(numpy.ascontiguousarray(a)).to(dev))
+                return lam.cpu().numpy(), w.cpu().numpy()
+        except ImportError:
+            pass
+    if single:
+        a = a.astype(numpy.complex64 if numpy.iscomplexobj(a) else numpy.float32)
+    return sla.eigh(a, driver='evd', overwrite_a=True, check_finite=False)
 
 
 def _as_matrix(A, arch):
@@ -374,7 +403,7 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
         B = numpy.eye(k) + E / 2 - E2 / 8
         Bi = numpy.eye(k) - E / 2 + 3 * E2 / 8
     else:
-        mu, U = sla.eigh(H, driver='evd')
+        mu, U = _eigh(H)
         keep = mu > numpy.finfo(dtype).eps * k * max(mu[-1], 0.0)
         if not numpy.any(keep):
             keep[-1] = True
@@ -382,12 +411,8 @@ def _orthogonal_times_orthonormal(left, right, diagonal=True):
         B = U * numpy.sqrt(mu)[None, :]
         Bi = U / numpy.sqrt(mu)[None, :]
     core = B.conj().T @ G @ B
-    if numpy.dtype(dtype).itemsize // (2 if numpy.dtype(dtype).kind == 'c' else 1) == 4 and k >= 256:
-        # single-precision data: the rotation is applied to single-precision blocks anyway, and the k x k
-        # eigenproblem is the cost of an update once k reaches the thousands (k = 1400: 0.7 s in double on the
-        # box's host cores against 0.05 s of dense products) -- half of it in single
-        core = core.astype(numpy.complex64 if numpy.dtype(dtype).kind == 'c' else numpy.float32)
-    lam, W = sla.eigh(core, driver='evd', overwrite_a=True, check_finite=False)
+    single = numpy.dtype(dtype).itemsize // (2 if numpy.dtype(dtype).kind == 'c' else 1) == 4 and k >= 256
+    lam, W = _eigh(core, single)
     W = W.astype(wide)
     order = numpy.argsort(-lam)
     W = W[:, order]
