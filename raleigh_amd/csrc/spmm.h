@@ -83,6 +83,7 @@ struct rlh_csr {
   int64_t stk_sched_part_len[2];
   int stk_grid_part[2];
   int stk_aligned;         // every staging group of the stacks starts on a multiple of 8 columns
+  int stk_overhang;        // columns (< 8) the last staging group reaches past n_cols: the callers' leading dimensions must cover them
   double stk_staged;       // staged elements per row and vector (diagnostic; the unstacked layout's: well_staged)
   double well_staged;
   // 256-row interleaved layout (any row length, any type)
@@ -154,6 +155,9 @@ struct Win { int32_t start, len, off; };        // off: position of the window i
 // window at the far end is moved left instead of being padded past the last column).  Returns the
 // number of staged columns (a multiple of `round_groups` * gs); `ws` is left with at least one window.
 // (`cols`: the referenced columns in any order, duplicates allowed; sorted in place)
+// (`nc` may be the column count rounded up to a multiple of 8 -- the stacked layout: a window at the far end then
+// still starts on a multiple of 8 and hangs over the last column by at most 7, which the leading dimension of the
+// caller's block must cover; the kernels that take it check that at launch)
 static inline int32_t find_windows_of(std::vector<int32_t> &cols, int64_t nc, int gap, int gs, int round_groups,
                                       std::vector<Win> &ws) {
   std::sort(cols.begin(), cols.end());

@@ -807,6 +807,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {           // ro
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+// p' = cy y + cp p + cb (b - t) with the roundings pinned (left to the compiler, the two kernels that share this step
+// contracted it differently: one bfloat16 ulp apart in 3 of 10^5 elements)
+__device__ __forceinline__ float cheb_update(float cy, float y, float cp, float p, float cb, float b, float t) {
+  return __fmaf_rn(cy, y, __fmaf_rn(cp, p, __fmul_rn(cb, __fsub_rn(b, t))));
+}
 struct alignas(16) Bf8 { unsigned short e[8]; };
 struct alignas(8) Bf8U { unsigned short e[8]; };                           // staging piece: groups start on multiples of 4 columns
 
@@ -925,14 +930,13 @@ __global__ __launch_bounds__(1024) void well_cheb_bf16_kernel(const WellMeta *__
         Bf8 out;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          out.e[k] = f32_to_bf16(cy * bf16_to_f32(yv.e[k]) + cp * bf16_to_f32(pv.e[k]) +
-                                 cb * (bf16_to_f32(bv.e[k]) - t8[k]));
+          out.e[k] = f32_to_bf16(cheb_update(cy, bf16_to_f32(yv.e[k]), cp, bf16_to_f32(pv.e[k]), cb, bf16_to_f32(bv.e[k]), t8[k]));
         *reinterpret_cast<Bf8 *>(pp) = out;
       } else if (mine) {                           // the last rows of the matrix
         unsigned short *pq = P + (int64_t)j * ldp + r8;
         const unsigned short *bq = B + (int64_t)j * ldb + r8, *yq = Yk + (int64_t)j * ldy + r8;
         for (int k = 0; k < 8 && r8 + k < n_rows; ++k)
-          pq[k] = f32_to_bf16(cy * bf16_to_f32(yq[k]) + cp * bf16_to_f32(pq[k]) + cb * (bf16_to_f32(bq[k]) - t8[k]));
+          pq[k] = f32_to_bf16(cheb_update(cy, bf16_to_f32(yq[k]), cp, bf16_to_f32(pq[k]), cb, bf16_to_f32(bq[k]), t8[k]));
       }
     };
     stage_load(0, stA);
@@ -1010,6 +1014,181 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
     if (vec && whole) return launch_well_we<T, WMAX, EPL>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
   }
   return launch_well_we<T, WMAX, 1>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, cheb);
+}
+
+// ------------------------------------------------------------------ bfloat16 Chebyshev step on the stacks
+// The fused step of well_cheb_bf16_kernel on the stacked layout, staged by the same LDS-DMA ring as well_stack_dma_kernel.
+// At the block size the driver uses for ten eigenpairs (16 vectors) the kernel above spends its time at block
+// boundaries -- two steps of eight vectors per block, 3.8 TB/s of algorithmic traffic (profiles/r03_spmm_stack.txt) --
+// so here:  ring of four 16 KB slots, one vector's bfloat16 image each (three vectors in flight);  one step = one vector
+// (counted wait, barrier, DMA three vectors ahead, the row products of the stack's two members into registers);  every
+// eight vectors the results go through a wave-private tile [vector][row] and come back as eight consecutive rows of one
+// vector per lane, so that y, p, b are read and p is written as 16-byte pieces.
+// Those operands (three quarters of the step's traffic) are LDS-DMAs too -- into a wave-private area, 1 KB per operand
+// and member, issued at the start of the group of eight: as ordinary loads they did NOT complete in order with the
+// DMAs (a counted wait on a DMA issued after them returned with their registers still in flight: NaNs at 215^3, none
+// in the small tests), and a vmcnt(0) for them drains the ring.  Every wait counts the operations the wave has issued
+// since the DMA it waits for: the DMAs of the later vectors and -- for the first three vectors of a group, whose DMAs
+// are issued before them -- the group's 3 nmem operand DMAs and the nmem stores of the previous group.
+constexpr int kBfRing = 4;
+constexpr int kBfSlotBytes = 16 * 1024;            // ng <= 128 groups of 64 two-byte elements
+constexpr int kBfOperandBytes = 6 * 1024;          // per wave: [member][p, b, y] x 64 lanes x 16 bytes (its first 2 KB double as the tile)
+
+template <int R>
+__global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMeta *__restrict__ meta,
+                                                                    const int32_t *__restrict__ member,
+                                                                    const int32_t *__restrict__ gsrc,
+                                                                    const uint16_t *__restrict__ idx,
+                                                                    const float *__restrict__ vals, int64_t n_rows,
+                                                                    const int32_t *__restrict__ sched, int64_t sched_len,
+                                                                    const unsigned short *__restrict__ Yk, int64_t ldy,
+                                                                    int64_t n_own, const unsigned short *__restrict__ H,
+                                                                    int64_t ldh, unsigned short *__restrict__ P, int64_t ldp,
+                                                                    const unsigned short *__restrict__ B, int64_t ldb,
+                                                                    int m, float cy, float cp, float cb) {
+  constexpr int WMAX = 8, NB = kBfRing, D = NB - 1, SLOT = kBfSlotBytes;
+  static_assert(D == 3 && R * 3 * 1024 <= kBfOperandBytes, "the wait counts below assume DMAs three steps ahead");
+  extern __shared__ __align__(16) char ldsb[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned opbase = (unsigned)(NB * SLOT) + (unsigned)wave * (unsigned)kBfOperandBytes;   // this wave's operand area
+  const int c8 = lane >> 3, rg = lane & 7;         // epilogue: vector c8 of the group, rows 8 rg .. 8 rg + 7 of the wave's 64
+  auto dma16 = [&](const void *g, unsigned dst) {  // 16 bytes per lane to the LDS at dst + 16 lane (dst wave-uniform)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  for (int64_t pos = blockIdx.x; pos < sched_len; pos += gridDim.x) {
+    const int64_t sb = sched[pos];
+    if (sb < 0) continue;
+    const WellMeta mt = meta[sb];
+    const int ng = mt.width_ng >> 8;               // a multiple of 8, <= 128
+    int64_t row0[R];                               // first of this wave's 64 rows in member r
+    float v[R][WMAX];
+    unsigned ixb[R][WMAX / 2];
+    bool whole = true;
+    int nmem = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int32_t mb = member[sb * R + r];
+      if (mb >= 0) {
+        nmem = r + 1;
+        whole = whole && ((int64_t)mb + 1) * kWellRows <= n_rows;
+      }
+      row0[r] = mb >= 0 ? (int64_t)mb * kWellRows + (int64_t)wave * 64 : n_rows;
+      unsigned px[WMAX];
+      well_load_entries<float, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
+#pragma unroll
+      for (int t = 0; t < WMAX; t += 2) ixb[r][t / 2] = px[t] | (px[t + 1] << 16);
+    }
+    // one 16-byte piece per lane = 8 elements: a wave's DMA covers 8 groups; wave w moves piece w of the ng / 8
+    const int mine = __builtin_amdgcn_readfirstlane(wave < ng / 8 ? 1 : 0);
+    int scol;
+    {
+      int q = wave * 8;
+      if (q > ng - 8) q = ng - 8;
+      scol = gsrc[mt.goff + q + lane / 8] + (lane % 8) * 8;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int t = 0; t < WMAX; ++t) asm volatile("" : "+v"(v[r][t]));
+#pragma unroll
+      for (int t = 0; t < WMAX / 2; ++t) asm volatile("" : "+v"(ixb[r][t]));
+    }
+    asm volatile("" : "+v"(scol));
+    auto issue = [&](int j) {
+      if (!mine) return;
+      dma16((scol < n_own ? Yk + (int64_t)j * ldy : H + (int64_t)j * ldh - n_own) + scol,
+            (unsigned)(j & (NB - 1)) * (unsigned)SLOT + (unsigned)wave * 1024u);
+    };
+    __builtin_amdgcn_s_barrier();                  // every wave is done with the previous stack's slots
+    for (int j = 0; j < D && j < m; ++j) issue(j);
+    for (int j0 = 0; j0 < m; j0 += 8) {
+      const int cnt = m - j0 < 8 ? m - j0 : 8;     // vectors of this group
+      // this lane's operands of the update: rows r8 .. r8 + 7 of vector j0 + c8 (clamped where the lane has none)
+      const int jv = j0 + c8;
+      const int jc = jv < m ? jv : m - 1;
+      const bool act = c8 < cnt;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r >= nmem) break;
+        const int64_t r8 = row0[r] + rg * 8;
+        const int64_t rc = r8 + 8 <= n_rows ? r8 : 0;
+        dma16(P + (int64_t)jc * ldp + rc, opbase + (unsigned)(r * 3 + 0) * 1024u);
+        dma16(B + (int64_t)jc * ldb + rc, opbase + (unsigned)(r * 3 + 1) * 1024u);
+        dma16(Yk + (int64_t)jc * ldy + rc, opbase + (unsigned)(r * 3 + 2) * 1024u);
+      }
+      float acc[R][8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][jj] = 0.f;
+        if (jj < cnt) {
+          const int j = j0 + jj;
+          const int later = m - 1 - j < D - 1 ? m - 1 - j : D - 1;
+          if (whole) wait_vm_outstanding(later * mine + (jj < D ? 3 * nmem + (j0 > 0 ? nmem : 0) : 0));
+          else wait_vm_le<0>();
+          __builtin_amdgcn_s_barrier();
+          if (j + D < m) issue(j + D);
+          unsigned boff = (unsigned)(j & (NB - 1)) * (unsigned)SLOT;
+          asm volatile("" : "+s"(boff));
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (r >= nmem) break;
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < WMAX; t += 2) {
+              unsigned w = ixb[r][t / 2];
+              asm volatile("" : "+v"(w));
+              a = fmaf(v[r][t], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + ((w & 0xffffu) * 2u + boff))), a);
+              a = fmaf(v[r][t + 1], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + ((w >> 16) * 2u + boff))), a);
+            }
+            acc[r][jj] = a;
+          }
+        }
+      }
+      // the operands have landed with the DMA of the group's last vector, which was issued after them -- unless the
+      // group is so short that it was not (or this wave issues no vector DMAs and its last wait was for less)
+      if (cnt <= D || !mine || !whole) wait_vm_le<0>();
+      // the update of this group, member by member; the member's operands first (their area doubles as the tile)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r >= nmem) break;
+        union { rlh_u32x4e u; unsigned short e[8]; } pu, bu, yu, ou;
+        pu.u = *reinterpret_cast<const rlh_u32x4e *>(ldsb + opbase + (unsigned)(r * 3 + 0) * 1024u + (unsigned)lane * 16u);
+        bu.u = *reinterpret_cast<const rlh_u32x4e *>(ldsb + opbase + (unsigned)(r * 3 + 1) * 1024u + (unsigned)lane * 16u);
+        yu.u = *reinterpret_cast<const rlh_u32x4e *>(ldsb + opbase + (unsigned)(r * 3 + 2) * 1024u + (unsigned)lane * 16u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (read before the tile overwrites them)
+        float *tile = reinterpret_cast<float *>(ldsb + opbase + (unsigned)(r * 3) * 1024u);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) tile[jj * 64 + lane] = acc[r][jj];
+        float t8[8];
+        {
+          const float4 lo = *reinterpret_cast<const float4 *>(tile + c8 * 64 + rg * 8);
+          const float4 hi = *reinterpret_cast<const float4 *>(tile + c8 * 64 + rg * 8 + 4);
+          t8[0] = lo.x; t8[1] = lo.y; t8[2] = lo.z; t8[3] = lo.w;
+          t8[4] = hi.x; t8[5] = hi.y; t8[6] = hi.z; t8[7] = hi.w;
+        }
+        const int64_t r8 = row0[r] + rg * 8;
+        if (whole || r8 + 8 <= n_rows) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            ou.e[k] = f32_to_bf16(cheb_update(cy, bf16_to_f32(yu.e[k]), cp, bf16_to_f32(pu.e[k]), cb, bf16_to_f32(bu.e[k]), t8[k]));
+          if (act) *reinterpret_cast<rlh_u32x4e *>(P + (int64_t)jv * ldp + r8) = ou.u;
+        } else if (act && r8 < n_rows) {           // the last rows of the matrix
+          unsigned short *pq = P + (int64_t)jv * ldp + r8;
+          const unsigned short *bq = B + (int64_t)jv * ldb + r8, *yq = Yk + (int64_t)jv * ldy + r8;
+          for (int k = 0; k < 8 && r8 + k < n_rows; ++k)
+            pq[k] = f32_to_bf16(cheb_update(cy, bf16_to_f32(yq[k]), cp, bf16_to_f32(pq[k]), cb, bf16_to_f32(bq[k]), t8[k]));
+        }
+      }
+      // (the next group's operand DMAs overwrite the area: this wave's reads of it are done -- its own LDS operations
+      // complete in order, and t8 has been consumed by the arithmetic above)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
 }
 
 template <typename T>
@@ -1099,6 +1278,10 @@ static int stack_dispatch(rlh_csr *h, int part, int64_t m, const T *X, int64_t l
   if (h->stk_blocks == 0 || env_int("RLH_SPMM_STACK", 1) == 0) return 0;
   const bool dma = h->stk_gmax * 64 * (int)sizeof(T) <= StkRing<T>::SLOT && (cplx || env_int("RLH_SPMM_STACK_DMA", 1) != 0);
   if (cplx && !dma) return 0;
+  // the last staging group may reach up to 7 columns past n_cols: inside the block's leading dimension, or not this way
+  if (h->stk_overhang > 0 && (H != nullptr && n_own != h->n_cols ? ldh < h->n_cols - n_own + h->stk_overhang
+                                                                  : ldx < h->n_cols + h->stk_overhang))
+    return 0;
   if (part != 0 || H != nullptr) {
     if (!dma || (H != nullptr && n_own != h->n_cols && !(h->stk_aligned && n_own % EPL == 0))) return 0;
     if (part != 0)
@@ -1440,6 +1623,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
     }
   }
   int64_t nst = (int64_t)members.size() / R;
+  const int64_t nc8 = (h->n_cols + 7) & ~(int64_t)7;                    // windows may end here: aligned starts at the far end too
   std::vector<std::vector<Win>> swins((size_t)nst);
   std::vector<int32_t> ngroups((size_t)nst, 0);
   auto analyse = [&](int64_t count) {
@@ -1453,7 +1637,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
         const int64_t r0 = mb * kWellRows, r1 = std::min<int64_t>(r0 + kWellRows, n);
         cols.insert(cols.end(), indices + indptr[r0], indices + indptr[r1]);
       }
-      ngroups[(size_t)sb] = find_windows_of(cols, h->n_cols, 32, 64, 8, swins[(size_t)sb]) / 64;
+      ngroups[(size_t)sb] = find_windows_of(cols, nc8, 32, 64, 8, swins[(size_t)sb]) / 64;
     });
   };
   analyse(nst);
@@ -1526,8 +1710,11 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       }
     }
   });
-  for (int64_t g = 0; g < goff; ++g)
-    if ((int64_t)gsrc[(size_t)g] + 64 > h->n_cols) return 0;            // 16-byte staging needs whole groups
+  h->stk_overhang = 0;
+  for (int64_t g = 0; g < goff; ++g) {
+    if ((int64_t)gsrc[(size_t)g] + 64 > nc8) return 0;                  // 16-byte staging needs whole groups
+    if ((int64_t)gsrc[(size_t)g] + 64 > h->n_cols) h->stk_overhang = (int)(nc8 - h->n_cols);
+  }
   h->stk_aligned = 1;
   for (int64_t g = 0; g < goff; ++g)
     if (gsrc[(size_t)g] & 7) h->stk_aligned = 0;
@@ -1628,7 +1815,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->well_ratio = 0.0; h->well_sched = nullptr; h->well_sched_len = 0; h->well_grid = 0; h->well_inbounds = 0; h->well_aligned = 0;
   h->stk_blocks = 0; h->stk_meta = nullptr; h->stk_member = nullptr; h->stk_gsrc = nullptr; h->stk_idx = nullptr;
   h->stk_split_at = -1; h->stk_sched_part[0] = h->stk_sched_part[1] = nullptr; h->stk_sched_part_len[0] = h->stk_sched_part_len[1] = 0;
-  h->stk_grid_part[0] = h->stk_grid_part[1] = 0; h->stk_aligned = 0; h->stk_gmax = 0;
+  h->stk_grid_part[0] = h->stk_grid_part[1] = 0; h->stk_aligned = 0; h->stk_gmax = 0; h->stk_overhang = 0;
   h->stk_vals = nullptr; h->stk_sched = nullptr; h->stk_sched_len = 0; h->stk_grid = 0; h->stk_staged = 0.0; h->well_staged = 0.0;
   h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
   h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
@@ -1810,15 +1997,39 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
                   ((uintptr_t)Y16 % 16) == 0 && ((uintptr_t)P16 % 16) == 0 && ((uintptr_t)B16 % 16) == 0,
               "rlh_spmm_cheb_bf16: blocks must be 16-byte aligned with leading dimensions that are multiples of 8");
   Context &c = ctx();
+  const unsigned short *Y = (const unsigned short *)Y16, *B = (const unsigned short *)B16;
+  const unsigned short *H = H16 ? (const unsigned short *)H16 : Y;
+  unsigned short *P = (unsigned short *)P16;
+  // the stacked layout (8 elements per 16-byte piece: groups on multiples of 8 columns, images of at most 128 groups)
+  if (h->stk_blocks > 0 && h->stk_aligned && h->stk_gmax <= kBfSlotBytes / 128 && env_int("RLH_SPMM_STACK", 1) != 0 &&
+      env_int("RLH_SPMM_STACK_BF16", 1) != 0 &&
+      (h->stk_overhang == 0 || (H16 != nullptr && n_own != h->n_cols ? ldh >= h->n_cols - n_own + h->stk_overhang
+                                                                      : ldy >= h->n_cols + h->stk_overhang))) {
+    if (part != 0)
+      if (int rc = stack_split(h, n_own)) return rc;
+    const int32_t *ssched = part == 0 ? h->stk_sched : h->stk_sched_part[part - 1];
+    const int64_t ssched_len = part == 0 ? h->stk_sched_len : h->stk_sched_part_len[part - 1];
+    const int sgrid = part == 0 ? h->stk_grid : h->stk_grid_part[part - 1];
+    if (sgrid == 0) return 0;
+    static bool attr = false;
+    constexpr int lds = kBfRing * kBfSlotBytes + 16 * kBfOperandBytes;
+    if (!attr) {
+      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&well_stack_cheb_bf16_kernel<kStkR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, h->stk_meta,
+                       h->stk_member, h->stk_gsrc, h->stk_idx, (const float *)h->stk_vals, h->n_rows, ssched, ssched_len, Y,
+                       ldy, n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp, (float)cb);
+    RLH_HIP(hipGetLastError());
+    return 0;
+  }
   if (part != 0)
     if (int rc = well_split(h, n_own)) return rc;
   const int32_t *sched = part == 0 ? h->well_sched : h->well_sched_part[part - 1];
   const int64_t sched_len = part == 0 ? h->well_sched_len : h->well_sched_part_len[part - 1];
   const int64_t nb = part == 0 ? h->well_grid : h->well_grid_part[part - 1];
   if (nb == 0) return 0;
-  const unsigned short *Y = (const unsigned short *)Y16, *B = (const unsigned short *)B16;
-  const unsigned short *H = H16 ? (const unsigned short *)H16 : Y;
-  unsigned short *P = (unsigned short *)P16;
 #define RLH_BF_LAUNCH(W)                                                                                          \
   hipLaunchKernelGGL((well_cheb_bf16_kernel<W>), dim3((unsigned)nb), dim3(1024), 0, c.stream, h->well_meta,       \
                      h->well_gsrc, h->well_idx, (const float *)h->well_vals, h->n_rows, sched, sched_len, Y, ldy, \

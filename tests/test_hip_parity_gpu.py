@@ -992,6 +992,98 @@ def test_fused_chebyshev_step_bf16_row_shard(rows):
     assert np.all(np.abs(got - exact) <= 2.0 ** -8 * np.abs(exact) + 1e-6)
 
 
+@pytest.mark.parametrize('m', [1, 7, 8, 13, 16, 29])
+def test_fused_chebyshev_step_bf16_on_stacks(monkeypatch, m):
+    """The bfloat16 step on the stacked layout (LDS-DMA ring of eight slots, groups of eight vectors; forced on a
+    matrix too small to get the stacks by default: 113 row blocks, so one stack of a single member, ragged last block):
+    against float32 NumPy on the same bfloat16 inputs, and bit for bit against the unstacked kernel."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    A = lap3d(70, 53, 31, 1.0, 1.01, 1.02).astype(np.float32)
+    n = A.shape[0]
+    rng = np.random.default_rng(50 + m)
+    y0, p0, b0 = (ops.bf16_round(rng.standard_normal((m, n)).astype(np.float32)) for _ in range(3))
+    op = SparseSymmetricMatrix(A)
+    assert op.supports_bf16() and op.layout()[3] == 57
+
+    def run():
+        blocks = []
+        for a in (y0, p0, b0):
+            blk = Bf16Block(n, m)
+            blk.pack(Vectors(a), 1.0)
+            blocks.append(blk)
+        y, p, b = blocks
+        op.cheb_step_bf16(m, y, p, b, 1.3, -0.3, 0.01)
+        out = Vectors(n, m, data_type=np.float32)
+        p.unpack(out)
+        chk = Vectors(n, m, data_type=np.float32)
+        y.unpack(chk)
+        assert np.array_equal(chk.data(), y0)
+        return out.data()
+    got = run()
+    A64 = sp.csr_matrix(A).astype(np.float64)
+    t = (A64 @ y0.T.astype(np.float64)).T
+    exact = 1.3 * y0 + -0.3 * p0 + 0.01 * (b0 - t)
+    # half a bfloat16 ulp of the result + the float32 rounding of the sum (entries of 1e4 here: a result that sits
+    # on a rounding tie may go either way)
+    mag = 1.3 * np.abs(y0) + 0.3 * np.abs(p0) + 0.01 * (np.abs(b0) + (abs(A64) @ np.abs(y0).T.astype(np.float64)).T)
+    assert np.all(np.abs(got - exact) <= 2.0 ** -8 * np.abs(exact) + 8 * 2.0 ** -24 * mag)
+    monkeypatch.setenv('RLH_SPMM_STACK', '0')
+    assert np.array_equal(run(), got)
+
+
+def test_fused_chebyshev_step_bf16_on_stacks_row_shard(monkeypatch):
+    """... and on a row shard: pieces right of the own / halo boundary from the bfloat16 halo block, part 1 (NaNs for
+    the halo) + part 2 = the whole step.  Planes of three row blocks (64 x 48)."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    A = lap3d(64, 48, 30, 1.0, 1.01, 1.02).astype(np.float32)
+    n = A.shape[0]
+    r0, r1 = 3072 * 4 + 104, 3072 * 26 + 777
+    loc = sp.csr_matrix(A[r0:r1])
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    nown = r1 - r0
+    n_own_pad = -(-nown // 8) * 8
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(nown)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    nh = -(-len(halo) // 8) * 8
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr), shape=(nown, n_own_pad + nh))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    assert op.layout()[0] == 'well' and op.stacks()[0] > 0
+    rng = np.random.default_rng(4)
+    m = 12
+    y0 = ops.bf16_round(rng.standard_normal((m, n)).astype(np.float32))
+    p0, b0 = (ops.bf16_round(rng.standard_normal((m, nown)).astype(np.float32)) for _ in range(2))
+
+    def block(a, rows_alloc):
+        blk = Bf16Block(rows_alloc, m)
+        pad = np.zeros((m, rows_alloc), dtype=np.float32)
+        pad[:, :a.shape[1]] = a
+        blk.pack(Vectors(pad), 1.0)
+        return blk
+    y, p, b = block(y0[:, r0:r1], n_own_pad), block(p0, n_own_pad), block(b0, n_own_pad)
+    hgood = block(y0[:, halo], nh)
+    hbad = block(np.full((m, len(halo)), np.nan, dtype=np.float32), nh)
+    op.cheb_step_bf16(m, y, p, b, 1.3, -0.3, 0.01, hbad.ptr(), hbad.ld, part=1)
+    op.cheb_step_bf16(m, y, p, b, 1.3, -0.3, 0.01, hgood.ptr(), hgood.ld, part=2)
+    out = Vectors(n_own_pad, m, data_type=np.float32)
+    p.unpack(out)
+    A64 = sp.csr_matrix(A[r0:r1]).astype(np.float64)
+    t = (A64 @ y0.T.astype(np.float64)).T
+    exact = 1.3 * y0[:, r0:r1] + -0.3 * p0 + 0.01 * (b0 - t)
+    mag = 1.3 * np.abs(y0[:, r0:r1]) + 0.3 * np.abs(p0) + 0.01 * (np.abs(b0) + (abs(A64) @ np.abs(y0).T.astype(np.float64)).T)
+    got = out.data()[:, :nown]
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - exact) <= 2.0 ** -8 * np.abs(exact) + 8 * 2.0 ** -24 * mag)
+
+
 # ---------------------------------------------------------------- interleaved layout: wide rows, every type
 @pytest.mark.parametrize('key', KEYS)
 @pytest.mark.parametrize('m,nv', [(1, 0), (5, 0), (16, 0), (33, 0), (16, 8), (40, 32), (7, 16), (9, 4)])

@@ -1,9 +1,7 @@
 #!/bin/bash
-set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_pca_update_gpu.py tests/test_pca_complex_gpu.py -x -q -m gpu > $O/pca_tests.txt 2>&1 || { tail -30 $O/pca_tests.txt | cut -c1-200; exit 1; }
-tail -3 $O/pca_tests.txt
-PCA_UPDATE_PROFILE=1 timeout -k 10 600 python tools/pca_update_bench.py > $O/pca_update_now.txt 2>&1 || { tail -20 $O/pca_update_now.txt; exit 1; }
-head -22 $O/pca_update_now.txt | cut -c1-170
-RLH_DEVICE_EIGH=0 timeout -k 10 600 python tools/pca_update_bench.py > $O/pca_update_host.txt 2>&1 || { tail -20 $O/pca_update_host.txt; exit 1; }
-head -4 $O/pca_update_host.txt | cut -c1-170
+timeout -k 10 900 python -m pytest tests/test_hip_parity_gpu.py tests/test_driver_gpu.py -x -q -m gpu -k "bf16 or cheb or driver or Cheb" > $O/stack_tests.txt 2>&1 || { tail -40 $O/stack_tests.txt | cut -c1-200; exit 1; }
+tail -3 $O/stack_tests.txt
+timeout -k 10 300 python tools/bf16_check.py 215 16 2>&1 | grep "finite\|vectors\|row blocks" | cut -c1-200
+timeout -k 10 300 python tools/bf16_check.py 215 13 2>&1 | grep "finite\|vectors\|row blocks" | cut -c1-200
+timeout -k 10 600 python tools/solve_lap.py --side 215 --cheb 32 --ratio 7000 --low --bf16 2>&1 | grep "status\|max rel\|Error" | cut -c1-200
