@@ -1017,24 +1017,25 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
 }
 
 // ------------------------------------------------------------------ bfloat16 Chebyshev step on the stacks
-// The fused step of well_cheb_bf16_kernel on the stacked layout, staged by the same LDS-DMA ring as well_stack_dma_kernel.
-// At the block size the driver uses for ten eigenpairs (16 vectors) the kernel above spends its time at block
-// boundaries -- two steps of eight vectors per block, 3.8 TB/s of algorithmic traffic (profiles/r03_spmm_stack.txt) --
-// so here:  ring of four 16 KB slots, one vector's bfloat16 image each (three vectors in flight);  one step = one vector
-// (counted wait, barrier, DMA three vectors ahead, the row products of the stack's two members into registers);  every
-// eight vectors the results go through a wave-private tile [vector][row] and come back as eight consecutive rows of one
-// vector per lane, so that y, p, b are read and p is written as 16-byte pieces.
-// Those operands (three quarters of the step's traffic) are LDS-DMAs too -- into a wave-private area, 1 KB per operand
-// and member, issued at the start of the group of eight: as ordinary loads they did NOT complete in order with the
-// DMAs (a counted wait on a DMA issued after them returned with their registers still in flight: NaNs at 215^3, none
-// in the small tests), and a vmcnt(0) for them drains the ring.  Every wait counts the operations the wave has issued
-// since the DMA it waits for: the DMAs of the later vectors and -- for the first three vectors of a group, whose DMAs
-// are issued before them -- the group's 3 nmem operand DMAs and the nmem stores of the previous group.
-constexpr int kBfRing = 4;
-constexpr int kBfSlotBytes = 16 * 1024;            // ng <= 128 groups of 64 two-byte elements
+// The fused step of well_cheb_bf16_kernel on the stacked layout, staged by LDS-DMA like well_stack_dma_kernel.  At the
+// block size the driver uses for ten eigenpairs (16 vectors) the kernel above spends its time at block boundaries -- two
+// steps of eight vectors per block, 1.75 GB of algorithmic traffic in 457 us = 3.8 TB/s -- so here:
+//  * two slots of VPS = 2 bfloat16 images (16 KB each: ng <= 128 groups);  one step = VPS vectors: wait for the step's
+//    DMAs (issued during the step before), barrier, DMAs of the next step into the other slot, the row products of the
+//    stack's two members into registers.  (One vector per step with a ring of 2, 4 or 6 slots: 380 us; two per step: 363.)
+//  * every eight vectors the results go through a wave-private tile [vector][row] and come back as eight consecutive
+//    rows of one vector per lane, so that y, p, b are read and p is written as 16-byte pieces.  Those operands (three
+//    quarters of the step's traffic) are LDS-DMAs too -- into a wave-private area, 1 KB per operand and member, issued at
+//    the start of the group of eight: as ordinary loads they did NOT complete in order with the DMAs (a counted wait on
+//    a DMA issued after them returned with their registers still in flight: NaNs at 215^3, none in the small tests),
+//    and a vmcnt(0) for them would wait for the vectors in flight as well.
+//  * a step's DMAs are issued during the step before, so the only operations younger than them are, at the first step
+//    of a group, the group's 3 nmem operand DMAs and the nmem stores of the previous group: that is what the wait allows.
+constexpr int kBfImageBytes = 16 * 1024;           // ng <= 128 groups of 64 two-byte elements
+constexpr int kBfRingBytes = 64 * 1024;
 constexpr int kBfOperandBytes = 6 * 1024;          // per wave: [member][p, b, y] x 64 lanes x 16 bytes (its first 2 KB double as the tile)
 
-template <int R>
+template <int R, int VPS>
 __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMeta *__restrict__ meta,
                                                                     const int32_t *__restrict__ member,
                                                                     const int32_t *__restrict__ gsrc,
@@ -1046,13 +1047,13 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
                                                                     int64_t ldh, unsigned short *__restrict__ P, int64_t ldp,
                                                                     const unsigned short *__restrict__ B, int64_t ldb,
                                                                     int m, float cy, float cp, float cb) {
-  constexpr int WMAX = 8, NB = kBfRing, D = NB - 1, SLOT = kBfSlotBytes;
-  static_assert(D == 3 && R * 3 * 1024 <= kBfOperandBytes, "the wait counts below assume DMAs three steps ahead");
+  constexpr int WMAX = 8, IMG = kBfImageBytes, SLOT = VPS * IMG;       // two slots of VPS images
+  static_assert(R * 3 * 1024 <= kBfOperandBytes && 2 * SLOT <= kBfRingBytes && 8 % VPS == 0, "operand area; ring");
   extern __shared__ __align__(16) char ldsb[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned opbase = (unsigned)(NB * SLOT) + (unsigned)wave * (unsigned)kBfOperandBytes;   // this wave's operand area
+  const unsigned opbase = (unsigned)kBfRingBytes + (unsigned)wave * (unsigned)kBfOperandBytes;   // this wave's operand area
   const int c8 = lane >> 3, rg = lane & 7;         // epilogue: vector c8 of the group, rows 8 rg .. 8 rg + 7 of the wave's 64
   auto dma16 = [&](const void *g, unsigned dst) {  // 16 bytes per lane to the LDS at dst + 16 lane (dst wave-uniform)
     unsigned keep;
@@ -1098,13 +1099,18 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
       for (int t = 0; t < WMAX / 2; ++t) asm volatile("" : "+v"(ixb[r][t]));
     }
     asm volatile("" : "+v"(scol));
-    auto issue = [&](int j) {
+    auto issue = [&](int j, unsigned par) {        // the images of vectors j, j + 1 (clamped) into slot `par`
       if (!mine) return;
-      dma16((scol < n_own ? Yk + (int64_t)j * ldy : H + (int64_t)j * ldh - n_own) + scol,
-            (unsigned)(j & (NB - 1)) * (unsigned)SLOT + (unsigned)wave * 1024u);
+#pragma unroll
+      for (int u = 0; u < VPS; ++u) {
+        const int jv = j + u < m ? j + u : m - 1;
+        dma16((scol < n_own ? Yk + (int64_t)jv * ldy : H + (int64_t)jv * ldh - n_own) + scol,
+              par * (unsigned)SLOT + (unsigned)u * (unsigned)IMG + (unsigned)wave * 1024u);
+      }
     };
     __builtin_amdgcn_s_barrier();                  // every wave is done with the previous stack's slots
-    for (int j = 0; j < D && j < m; ++j) issue(j);
+    unsigned par = 0;                              // slot of the step in hand
+    issue(0, 0);
     for (int j0 = 0; j0 < m; j0 += 8) {
       const int cnt = m - j0 < 8 ? m - j0 : 8;     // vectors of this group
       // this lane's operands of the update: rows r8 .. r8 + 7 of vector j0 + c8 (clamped where the lane has none)
@@ -1122,36 +1128,43 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
       }
       float acc[R][8];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
+      for (int jj = 0; jj < 8; jj += VPS) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r][jj] = 0.f;
+        for (int u = 0; u < VPS; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r][jj + u] = 0.f;
         if (jj < cnt) {
           const int j = j0 + jj;
-          const int later = m - 1 - j < D - 1 ? m - 1 - j : D - 1;
-          if (whole) wait_vm_outstanding(later * mine + (jj < D ? 3 * nmem + (j0 > 0 ? nmem : 0) : 0));
+          if (whole) wait_vm_outstanding(jj == 0 ? 3 * nmem + (j0 > 0 ? nmem : 0) : 0);
           else wait_vm_le<0>();
           __builtin_amdgcn_s_barrier();
-          if (j + D < m) issue(j + D);
-          unsigned boff = (unsigned)(j & (NB - 1)) * (unsigned)SLOT;
+          const int jn = jj + VPS < cnt ? j + VPS : j0 + 8;          // first vector of the next step
+          if (jn < m) issue(jn, par ^ 1u);
+          unsigned boff = par * (unsigned)SLOT;
           asm volatile("" : "+s"(boff));
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            if (r >= nmem) break;
-            float a = 0.f;
+          for (int u = 0; u < VPS; ++u) {
 #pragma unroll
-            for (int t = 0; t < WMAX; t += 2) {
-              unsigned w = ixb[r][t / 2];
-              asm volatile("" : "+v"(w));
-              a = fmaf(v[r][t], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + ((w & 0xffffu) * 2u + boff))), a);
-              a = fmaf(v[r][t + 1], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + ((w >> 16) * 2u + boff))), a);
+            for (int r = 0; r < R; ++r) {
+              if (r >= nmem) break;
+              float a = 0.f;
+#pragma unroll
+              for (int t = 0; t < WMAX; t += 2) {
+                unsigned w = ixb[r][t / 2];
+                asm volatile("" : "+v"(w));
+                a = fmaf(v[r][t], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + ((w & 0xffffu) * 2u + boff))), a);
+                a = fmaf(v[r][t + 1], bf16_to_f32(*reinterpret_cast<const unsigned short *>(ldsb + ((w >> 16) * 2u + boff))), a);
+              }
+              acc[r][jj + u] = a;                   // (a vector past the block's last: computed on a repeated image, not used)
             }
-            acc[r][jj] = a;
+            boff += (unsigned)IMG;
           }
+          par ^= 1u;
         }
       }
-      // the operands have landed with the DMA of the group's last vector, which was issued after them -- unless the
-      // group is so short that it was not (or this wave issues no vector DMAs and its last wait was for less)
-      if (cnt <= D || !mine || !whole) wait_vm_le<0>();
+      // the operands have landed with the DMAs of the group's last step, issued after them -- unless the group has one
+      // step only (or this wave issues no vector DMAs)
+      if (cnt <= VPS || !mine || !whole) wait_vm_le<0>();
       // the update of this group, member by member; the member's operands first (their area doubles as the tile)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -2001,7 +2014,7 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
   const unsigned short *H = H16 ? (const unsigned short *)H16 : Y;
   unsigned short *P = (unsigned short *)P16;
   // the stacked layout (8 elements per 16-byte piece: groups on multiples of 8 columns, images of at most 128 groups)
-  if (h->stk_blocks > 0 && h->stk_aligned && h->stk_gmax <= kBfSlotBytes / 128 && env_int("RLH_SPMM_STACK", 1) != 0 &&
+  if (h->stk_blocks > 0 && h->stk_aligned && h->stk_gmax <= kBfImageBytes / 128 && env_int("RLH_SPMM_STACK", 1) != 0 &&
       env_int("RLH_SPMM_STACK_BF16", 1) != 0 &&
       (h->stk_overhang == 0 || (H16 != nullptr && n_own != h->n_cols ? ldh >= h->n_cols - n_own + h->stk_overhang
                                                                       : ldy >= h->n_cols + h->stk_overhang))) {
@@ -2011,16 +2024,23 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
     const int64_t ssched_len = part == 0 ? h->stk_sched_len : h->stk_sched_part_len[part - 1];
     const int sgrid = part == 0 ? h->stk_grid : h->stk_grid_part[part - 1];
     if (sgrid == 0) return 0;
-    static bool attr = false;
-    constexpr int lds = kBfRing * kBfSlotBytes + 16 * kBfOperandBytes;
-    if (!attr) {
-      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&well_stack_cheb_bf16_kernel<kStkR>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr = true;
-    }
-    hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, h->stk_meta,
-                       h->stk_member, h->stk_gsrc, h->stk_idx, (const float *)h->stk_vals, h->n_rows, ssched, ssched_len, Y,
-                       ldy, n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp, (float)cb);
+    constexpr int lds = kBfRingBytes + 16 * kBfOperandBytes;
+#define RLH_BF_STACK(VPS_)                                                                                            \
+    do {                                                                                                              \
+      static bool attr = false;                                                                                       \
+      if (!attr) {                                                                                                    \
+        RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&well_stack_cheb_bf16_kernel<kStkR, VPS_>),        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                \
+        attr = true;                                                                                                  \
+      }                                                                                                               \
+      hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR, VPS_>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, \
+                         h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx, (const float *)h->stk_vals, h->n_rows,  \
+                         ssched, ssched_len, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp,     \
+                         (float)cb);                                                                                  \
+    } while (0)
+    if (env_int("RLH_SPMM_BF16_VPS", 2) >= 2) RLH_BF_STACK(2);
+    else RLH_BF_STACK(1);
+#undef RLH_BF_STACK
     RLH_HIP(hipGetLastError());
     return 0;
   }
