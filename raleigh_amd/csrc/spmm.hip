@@ -626,12 +626,11 @@ __global__ __launch_bounds__(1024) void well_stack_kernel(const WellMeta *__rest
 // wave-uniform base + 16 * lane, which is exactly the staged image's layout) into a ring of four slots of one vector each:
 // no staging registers (the register-staged kernel above spills at R = 2 in fp64), no ds_write pass, and three vectors in
 // flight instead of two steps.  One step = one vector:  wait until its DMAs have landed (counted vmcnt: the DMAs of the
-// two later vectors and the Y stores issued since stay in flight);  barrier (every wave's pieces are there, and every
+// two later vectors stay in flight);  barrier (every wave's pieces are there, and every
 // wave is done with the slot the next DMA overwrites);  issue the DMAs of the vector three steps ahead;  row products
 // of this vector out of its slot and the R stores.  The compiler does not count asm loads, so every wait on the DMAs is
-// written here, from the number of vector-memory operations this wave has issued after them.  That needs the stores
-// issued unconditionally (a wave skipping them would wait for too little): a stack with a ragged member (the last row
-// block of the matrix) waits for vmcnt(0) instead.
+// written here, from the number of DMAs this wave has issued after them (LDS-DMAs complete in order among themselves);
+// a stack with a ragged member (the last row block of the matrix) waits for vmcnt(0) instead.
 // Timing-only builds (DBG, profiles/r03_spmm_stack.txt) put the floor of this access pattern -- DMAs, stores and the
 // entries, no LDS reads -- at 1.09 of the kernel's 1.15-1.20 ms on lap3d 215^3 fp64; a version whose ring ran on across
 // the stack boundaries, with the next stack's entries prefetched into a second register set, measured the same and is
@@ -690,7 +689,7 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
   constexpr int SLOT = StkRing<T>::SLOT;
   constexpr int EPL = 16 / (int)sizeof(T);         // elements per 16-byte piece
   constexpr int LPG = 64 / EPL;
-  static_assert((D - 1) * LD + D * R < 24, "wait_vm_outstanding's cases");
+  static_assert((D - 1) * LD + D * R < 24, "wait_vm_outstanding's cases");      // (10 + 6)
   extern __shared__ __align__(16) char ldsb[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -719,13 +718,16 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
 #pragma unroll
       for (int t = 0; t < WMAX; t += 2) ixb[r][t / 2] = px[t] | (px[t + 1] << 16);
     }
-    // a vector's image is ng / EPL pieces of 16 bytes per lane; wave w moves pieces w, w + 16, ...: `mine` of them (the
-    // waits below count per wave)
+    // a vector's image is ng / EPL pieces of 16 bytes per lane, moved by the first nw waves, LD pieces each at most: wave
+    // w takes pieces w, w + nw, ...: `mine` of them (the waits below count per wave; a wave with many pieces keeps more
+    // of the later vectors in flight behind the interleaved stores than sixteen waves with one or two each)
     int scol[LD];                                  // first column this lane fetches, per piece
-    const int mine = __builtin_amdgcn_readfirstlane((ng / EPL - wave + 15) / 16);
+    const int npieces = ng / EPL;
+    const int nw = __builtin_amdgcn_readfirstlane((npieces + LD - 1) / LD);
+    const int mine = __builtin_amdgcn_readfirstlane(wave < nw ? (npieces - wave + nw - 1) / nw : 0);
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      int q = (wave + 16 * i) * EPL;
+      int q = (wave + nw * i) * EPL;
       if (q > ng - EPL) q = ng - EPL;              // (a piece this wave does not have: any valid address)
       scol[i] = gsrc[mt.goff + q + lane / LPG] + (lane % LPG) * EPL;
     }
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
       for (int i = 0; i < LD; ++i) {
         if (i >= mine || (DBG & 1)) break;
         const T *g = (scol[i] < n_own ? src : hsrc) + scol[i];
-        unsigned dst = slot + (unsigned)(wave + 16 * i) * 1024u, keep;
+        unsigned dst = slot + (unsigned)(wave + nw * i) * 1024u, keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
       }
@@ -780,9 +782,13 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
     __builtin_amdgcn_s_barrier();
     for (int j = 0; j < D && j < m; ++j) issue(j);
     for (int j = 0; j < m; ++j) {
-      // operations issued after the DMAs of vector j: those of the later vectors in flight and the stores of the steps since
+      // DMAs issued after those of vector j: the later vectors in flight.  The stores of the last steps are younger too,
+      // but they are NOT counted as allowed: LDS-DMAs and ordinary vector-memory operations do not complete in order with
+      // each other (seen with loads in the bfloat16 kernel below), and a store that has completed early would let an
+      // unfinished DMA through the count; if they are still outstanding this waits for one more vector than necessary
+      // (RLH_SPMM_STACK_DBG & 16 counts them as before: the same time to within the noise).
       const int later = m - 1 - j < D - 1 ? m - 1 - j : D - 1;
-      if (whole) wait_vm_outstanding(((DBG & 1) ? 0 : later * mine) + ((DBG & 4) ? 0 : (j < D ? j : D) * nmem));
+      if (whole) wait_vm_outstanding(((DBG & 1) ? 0 : later * mine) + ((DBG & 16) ? (j < D ? j : D) * nmem : 0));
       else wait_vm_le<0>();
       __builtin_amdgcn_s_barrier();
       if (j + D < m) issue(j + D);
@@ -1029,8 +1035,8 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
 //    the start of the group of eight: as ordinary loads they did NOT complete in order with the DMAs (a counted wait on
 //    a DMA issued after them returned with their registers still in flight: NaNs at 215^3, none in the small tests),
 //    and a vmcnt(0) for them would wait for the vectors in flight as well.
-//  * a step's DMAs are issued during the step before, so the only operations younger than them are, at the first step
-//    of a group, the group's 3 nmem operand DMAs and the nmem stores of the previous group: that is what the wait allows.
+//  * a step's DMAs are issued during the step before, so the only DMAs younger than them are, at the first step of a
+//    group, the group's 3 nmem operand DMAs: that is what the wait allows.
 constexpr int kBfImageBytes = 16 * 1024;           // ng <= 128 groups of 64 two-byte elements
 constexpr int kBfRingBytes = 64 * 1024;
 constexpr int kBfOperandBytes = 6 * 1024;          // per wave: [member][p, b, y] x 64 lanes x 16 bytes (its first 2 KB double as the tile)
@@ -1135,7 +1141,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
           for (int r = 0; r < R; ++r) acc[r][jj + u] = 0.f;
         if (jj < cnt) {
           const int j = j0 + jj;
-          if (whole) wait_vm_outstanding(jj == 0 ? 3 * nmem + (j0 > 0 ? nmem : 0) : 0);
+          if (whole) wait_vm_outstanding(jj == 0 ? 3 * nmem : 0);       // (the previous group's stores: not counted as allowed, see above)
           else wait_vm_le<0>();
           __builtin_amdgcn_s_barrier();
           const int jn = jj + VPS < cnt ? j + VPS : j0 + 8;          // first vector of the next step
@@ -1215,7 +1221,7 @@ static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64
   constexpr bool cplx = std::is_same<T, c32>::value || std::is_same<T, c64>::value;
   if (dma) {
     constexpr int EPL = 16 / (int)sizeof(T);
-    const int ld = (h->stk_gmax + 16 * EPL - 1) / (16 * EPL);          // 16-byte pieces per wave and vector
+    const int ld = 5;                                                  // 16-byte pieces per issuing wave and vector (<= 80 pieces)
 #define RLH_STK_DMA(LD_, ...)                                                                                           \
     do {                                                                                                                \
       static bool attr_dma = false;                                                                                     \
@@ -1229,25 +1235,22 @@ static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64
                          (const T *)h->stk_vals, h->n_rows, sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m);   \
     } while (0)
     const int dbg = env_int("RLH_SPMM_STACK_DBG", 0);
-    if (dbg && ld == 3 && sizeof(T) == 8) {
-      if constexpr (sizeof(T) == 8) {
+    RLH_REQUIRE(h->stk_gmax <= 80 * EPL, "rlh_spmm: a stack of %d staging groups", h->stk_gmax);   // (a slot holds 40 or 80 pieces)
+    if (dbg && std::is_same<T, double>::value) {
+      if constexpr (std::is_same<T, double>::value) {
         switch (dbg) {
-          case 1: RLH_STK_DMA(3, , 1); break;
-          case 2: RLH_STK_DMA(3, , 2); break;
-          case 3: RLH_STK_DMA(3, , 3); break;
-          case 4: RLH_STK_DMA(3, , 4); break;
-          case 5: RLH_STK_DMA(3, , 5); break;
-          case 6: RLH_STK_DMA(3, , 6); break;
-          case 7: RLH_STK_DMA(3, , 7); break;
-          default: RLH_STK_DMA(3, , 8); break;
+          case 1: RLH_STK_DMA(5, , 1); break;
+          case 2: RLH_STK_DMA(5, , 2); break;
+          case 3: RLH_STK_DMA(5, , 3); break;
+          case 4: RLH_STK_DMA(5, , 4); break;
+          case 5: RLH_STK_DMA(5, , 5); break;
+          case 6: RLH_STK_DMA(5, , 6); break;
+          case 7: RLH_STK_DMA(5, , 7); break;
+          case 8: RLH_STK_DMA(5, , 8); break;
+          default: RLH_STK_DMA(5, , 16); break;
         }
       }
-    } else if (ld <= 1) RLH_STK_DMA(1);
-    else if (ld == 2) RLH_STK_DMA(2);
-    else if (ld == 3) RLH_STK_DMA(3);
-    else if (ld <= 5 && sizeof(T) == 16) {
-      if constexpr (sizeof(T) == 16) RLH_STK_DMA(5);         // (80 pieces of 1 KB in a slot of 80 KB)
-    } else RLH_REQUIRE(false, "rlh_spmm: a stack of %d staging groups", h->stk_gmax);
+    } else RLH_STK_DMA(5);
 #undef RLH_STK_DMA
     RLH_HIP(hipGetLastError());
     return 0;
@@ -1289,8 +1292,12 @@ static int stack_dispatch(rlh_csr *h, int part, int64_t m, const T *X, int64_t l
   constexpr int EPL = 16 / (int)sizeof(T);
   *done = false;
   if (h->stk_blocks == 0 || env_int("RLH_SPMM_STACK", 1) == 0) return 0;
-  const bool dma = h->stk_gmax * 64 * (int)sizeof(T) <= StkRing<T>::SLOT && (cplx || env_int("RLH_SPMM_STACK_DMA", 1) != 0);
+  bool dma = h->stk_gmax * 64 * (int)sizeof(T) <= StkRing<T>::SLOT && (cplx || env_int("RLH_SPMM_STACK_DMA", 1) != 0);
   if (cplx && !dma) return 0;
+  // float32, whole operator on own columns: the register-staged kernel (0.66 against 0.71 ms on lap3d 215^3 m = 32 -- with
+  // one or two DMA pieces per wave the waits, which do not count the interleaved stores as allowed, keep too little in
+  // flight; RLH_SPMM_STACK_DMA=2 takes the DMA kernel regardless)
+  if (sizeof(T) == 4 && !cplx && part == 0 && H == nullptr && env_int("RLH_SPMM_STACK_DMA", 1) < 2) dma = false;
   // the last staging group may reach up to 7 columns past n_cols: inside the block's leading dimension, or not this way
   if (h->stk_overhang > 0 && (H != nullptr && n_own != h->n_cols ? ldh < h->n_cols - n_own + h->stk_overhang
                                                                   : ldx < h->n_cols + h->stk_overhang))

@@ -582,12 +582,12 @@ def test_spmm_windowed_schedule_many_blocks(monkeypatch):
 
 @pytest.mark.parametrize('key', KEYS)
 @pytest.mark.parametrize('m', [1, 5, 13, 32])
-@pytest.mark.parametrize('dma', ['1', '0'])
+@pytest.mark.parametrize('dma', ['2', '0'])
 def test_spmm_stacked_blocks(monkeypatch, key, m, dma):
     """The stacked windowed layout (two overlapping 1024-row blocks per workgroup, rlh_csr_stacks) forced on matrices
     that are too small to get it by default: 70 x 53 x 31 lap3d has 113 row blocks -- an odd number, so one stack has a
-    single member -- and 115 010 rows, so the last block is ragged.  The LDS-DMA ring kernel, and (RLH_SPMM_STACK_DMA=0,
-    real types) the register-staged one; the complex types keep their interleaved layout beside the stacks.  Against the
+    single member -- and 115 010 rows, so the last block is ragged.  The LDS-DMA ring kernel (RLH_SPMM_STACK_DMA=2: for
+    float32 too), and (=0, real types) the register-staged one; the complex types keep their interleaved layout beside the stacks.  Against the
     oracle, and bit for bit (real types: same entry order per row) against the unstacked kernel on the same handle."""
     from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
     monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)

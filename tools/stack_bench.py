@@ -88,9 +88,10 @@ def main():
         variants += [('stacks, LDS-DMA', {'RLH_SPMM_STACK': '1'})]
     elif stacks:
         variants += [('stacks, register staging', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '0'}),
-                     ('stacks, LDS-DMA', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '1', 'RLH_SPMM_STACK_DBG': '0'})]
+                     ('stacks, LDS-DMA', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '2', 'RLH_SPMM_STACK_DBG': '0'})]
         if args.dbg:
-            variants += [('stacks, LDS-DMA, plain stores', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '1', 'RLH_SPMM_STACK_DBG': '8'})]
+            variants += [('stacks, LDS-DMA, plain stores', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '2', 'RLH_SPMM_STACK_DBG': '8'}),
+                         ('stacks, LDS-DMA, stores counted', {'RLH_SPMM_STACK': '1', 'RLH_SPMM_STACK_DMA': '2', 'RLH_SPMM_STACK_DBG': '16'})]
     # the variants take turns (one call each per round): the first calls of a process run up to 8 % slower than the
     # later ones, which a variant-after-variant comparison books to whoever goes first
     times = {name: [] for name, _ in variants}
