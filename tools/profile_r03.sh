@@ -23,18 +23,35 @@ run si_lap30_stats "" python3 $R/tools/si_bench.py 30 --m 8
 run gemm_d_stats "" python3 $R/tools/gemm_shapes.py --dtype d 20000x20000
 run gemm_z_stats "" python3 $R/tools/gemm_shapes.py --dtype z 20000x20000
 run gemm_d_mfma "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" python3 $R/tools/gemm_shapes.py --dtype d 20000x20000
+run solve_stats "" python3 $R/tools/solve_lap.py --side 215 --cheb 32 --ratio 7000 --low --bf16
+run stack_fetch "FETCH_SIZE" python3 $R/tools/stack_bench.py --lap 215 --reps 2
+(cd $R && timeout -k 10 300 python3 tools/stack_bench.py --lap 215 --reps 12 > $O/stack_ab.txt 2>&1; timeout -k 10 300 python3 tools/stack_bench.py --herm 126 --dtype z --m 64 --reps 12 >> $O/stack_ab.txt 2>&1; timeout -k 10 300 python3 tools/pca_update_bench.py >> $O/stack_ab.txt 2>&1) || echo "FAILED stack_ab"
 python3 - <<PY
 import csv, glob, collections, os
 O = "$O"
 def newest(p):
     g = glob.glob(p)
     return max(g, key=os.path.getmtime) if g else None
-for name in ("ilu_fe_stats", "ilu_lap100_stats", "si_lap30_stats", "gemm_d_stats", "gemm_z_stats"):
+for name in ("ilu_fe_stats", "ilu_lap100_stats", "si_lap30_stats", "gemm_d_stats", "gemm_z_stats", "solve_stats"):
     f = newest(O + "/%s/*/*kernel_stats.csv" % name)
     if not f: continue
     print("== %s (rocprofv3 --kernel-trace --stats)" % name)
     for r in list(csv.DictReader(open(f)))[:6]:
         print("  %-70s calls=%5s avg=%10.1f us  %5s%%" % (r["Name"].split("(")[0].replace("void rlh::", "")[:70], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+f = newest(O + "/stack_fetch/*/*counter_collection.csv")
+if f:
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "well_" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0].replace("void rlh::", "")[:60]].append(float(r["Counter_Value"]))
+    print("== stack_fetch (rocprofv3 --pmc FETCH_SIZE, KiB; x 2 on gfx950 for wide coalesced reads)")
+    for k, v in acc.items():
+        print("  %-60s FETCH_SIZE %.0f KiB -> %.2f GB read over the fabric" % (k, sum(v) / len(v), 2 * 1024 * sum(v) / len(v) / 1e9))
+try:
+    print("== stack_ab (tools/stack_bench.py, tools/pca_update_bench.py)")
+    print(open(O + "/stack_ab.txt").read())
+except OSError:
+    pass
 for name in ("gemm_d_mfma",):
     f = newest(O + "/%s/*/*counter_collection.csv" % name)
     if not f: continue
