@@ -24,6 +24,7 @@ update(), with the existing approximation A0 - e0 a0 ~ L0 R0 (n0 rows) and n1 ne
 
 import math
 import os
+import sys
 
 import numpy
 import scipy.linalg as sla
@@ -41,12 +42,15 @@ def _eigh(a, single=False):
     the thousands (k = 1400: 0.36-0.41 s per call with LAPACK on the GPU box's host cores, against 0.05 s for all the
     dense products of the update), so from k = 768 on the matrix goes to the vendor's dense eigensolver on the GPU
     through PyTorch (torch.linalg.eigh: 0.033 s at k = 1400, 0.08 s at 2800 -- what the reference hands to LAPACK,
-    raleigh/interfaces/lra.py:216-222, on the device the data lives on).  RLH_DEVICE_EIGH=0, or no PyTorch with a GPU:
+    raleigh/interfaces/lra.py:216-222, on the device the data lives on) -- in a process that has PyTorch imported
+    already (a row-sharded run, or the caller did): a cold `import torch` costs ~10 s on a fresh box, more than it saves
+    in one call; RLH_DEVICE_EIGH=2 imports it regardless, =0 never uses it.  Otherwise, or without a GPU in PyTorch:
     LAPACK on the host, as before -- in single precision if `single` (single-precision data, k >= 256: the rotation is
     applied to single-precision blocks anyway, and it halves the host time; on the device double costs the same as
     single and the vendor's single-precision solver orders close eigenvalues less reliably)."""
     k = a.shape[0]
-    if k >= _DEVICE_EIGH_MIN and os.environ.get('RLH_DEVICE_EIGH', '1') != '0':
+    mode = os.environ.get('RLH_DEVICE_EIGH', '1')
+    if k >= _DEVICE_EIGH_MIN and mode != '0' and (mode == '2' or 'torch' in sys.modules):
         try:
             import torch
             if torch.cuda.is_available():

@@ -42,6 +42,23 @@ def test_update_with_other_norms(golden_dir):
     cases.update_with_other_norms(golden_dir)
 
 
+@pytest.mark.parametrize('mode', ['2', '0'])
+def test_update_eigensolver_on_the_device_and_on_the_host(monkeypatch, mode):
+    """The k x k eigenproblems of an update at k ~ 900 through the vendor's eigensolver on the GPU (RLH_DEVICE_EIGH=2:
+    PyTorch imported if need be) and through LAPACK on the host (=0): the same components to the tolerance of the data."""
+    from raleigh_amd.interfaces import pca, pca_error
+    from oracle.pca_data import generate
+    monkeypatch.setenv('RLH_DEVICE_EIGH', mode)
+    np.random.seed(1)
+    A, sigma, u, v = generate(3000, 2000, 1000, pca=True)
+    m0 = pca(np.ascontiguousarray(A[:2400]), tol=0.05)
+    mean, trans, comps = pca(np.ascontiguousarray(A[2400:]), have=m0)
+    assert comps.shape[0] >= 768
+    cases.check_shape_of_result(A, mean, trans, comps)
+    em, ef = pca_error(A, mean, trans, comps)
+    assert ef < 0.055 and em < 0.03
+
+
 def test_reference_doctests_incremental_and_update():
     """generate(3000, 2000, 1000): pca(A, batch_size=1000, tol=0.05) -> 'max 2-norm 2e-02, Frobenius norm 4e-02';
     pca(A[:2400], tol=0.05) then pca(A[2400:], have=...) -> '2e-02, 5e-02' for all rows (pca.py:108-133).

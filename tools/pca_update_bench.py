@@ -9,7 +9,10 @@ ap.add_argument('--N', type=int, default=4000)
 ap.add_argument('--rank', type=int, default=2000)
 ap.add_argument('--batch', type=int, default=4000)
 ap.add_argument('--tol', type=float, default=0.05)
+ap.add_argument('--device-eigh', action='store_true', help='import PyTorch first: the k x k eigenproblems then go to the GPU')
 a = ap.parse_args()
+if a.device_eigh:
+    import torch  # noqa: F401
 from raleigh_amd.interfaces import pca, pca_error
 from raleigh_amd import _lib
 from oracle.pca_data import generate          # the reference's test-data generator (examples/pca/generate_matrix.py), restated
