@@ -584,6 +584,22 @@ __global__ __launch_bounds__(1024) void well_stack_kernel(const WellMeta *__rest
         boff += (unsigned)F * (unsigned)sizeof(T);
       }
     };
+    if constexpr (sizeof(T) >= 8) {
+      // one register set (two spill 36 bytes in fp64): the loads of step s + 1 are in flight during the arithmetic of step s
+      VecU<T, EPL> stA[SLOTS];
+      stage_load(0, stA);
+      stage_write(0, stA);
+      __syncthreads();
+      for (int s = 0; s + 1 < nsteps; ++s) {
+        stage_load(s + 1, stA);
+        compute(s);
+        stage_write(s + 1, stA);
+        __syncthreads();
+      }
+      compute(nsteps - 1);
+      __syncthreads();
+      continue;
+    }
     VecU<T, EPL> stA[SLOTS], stB[SLOTS];
     stage_load(0, stA);
     stage_load(nsteps > 1 ? 1 : 0, stB);
