@@ -72,6 +72,12 @@ struct rlh_csr {
   int32_t *stk_gsrc;       // device
   uint16_t *stk_idx;       // device
   void *stk_vals;          // device
+  // value dictionary of the stacks (constant-coefficient stencils repeat a few dozen rows of values: 27 for the 7-point
+  // Laplacian): per row the index of its 8-slot value tuple, and the table of distinct tuples -- 4 bytes per row
+  // instead of 8 values; nullptr when the rows have more than kStkMaxPatterns distinct tuples
+  int32_t *stk_pat;        // device, [stack][member][row of the block]
+  void *stk_table;         // device, [pattern][8 values]
+  int64_t stk_npat;
   int32_t *stk_sched;      // device
   int64_t stk_sched_len;
   int stk_grid;

@@ -15,6 +15,8 @@
 //  * sliced ELLPACK, slice height 64 (sell_spmm_kernel): no column locality.  One 8-byte gather of
 //    X per stored entry and vector; limited by the rate at which a CU retires per-lane gathers
 //    (profiles/r01_spmm_sweep2.txt), not by HBM: 34 % on the 7-point Laplacian.
+#include <unordered_map>
+
 #include "spmm.h"
 
 namespace rlh {
@@ -226,6 +228,31 @@ __device__ __forceinline__ void well_load_entries(const T *__restrict__ vals, co
   }
 }
 constexpr int kWellRows = 1024;
+constexpr int kStkMaxPatterns = 4096;
+
+// The same with the values out of the stacks' dictionary: the row's pattern index (4 bytes) and the 8 values of that
+// pattern (a few dozen 16-byte lines that stay in the L1 / L2 for the whole launch) instead of 8 values per row.
+template <typename T, int WMAX>
+__device__ __forceinline__ void well_load_entries_pat(const T *__restrict__ table, const int32_t *__restrict__ pat,
+                                                      const uint16_t *__restrict__ idx, int64_t eoff, int64_t prow, int tid,
+                                                      T (&v)[WMAX], unsigned (&pos)[WMAX]) {
+  constexpr int VPG = 16 / (int)sizeof(T) > 0 ? 16 / (int)sizeof(T) : 1;
+  const int32_t pid = pat[prow];
+#pragma unroll
+  for (int g = 0; g < WMAX / VPG; ++g) {
+    union { rlh_u32x4e u; T t[VPG]; } piece;
+    piece.u = *reinterpret_cast<const rlh_u32x4e *>(table + (int64_t)pid * WMAX + g * VPG);
+#pragma unroll
+    for (int k = 0; k < VPG; ++k) v[g * VPG + k] = piece.t[k];
+  }
+#pragma unroll
+  for (int g = 0; g < WMAX / 8; ++g) {
+    union { rlh_u32x4e u; unsigned short h[8]; } piece;
+    piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(idx + well_idx_index(eoff, g * 8, tid)));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pos[g * 8 + k] = (unsigned)piece.h[k];
+  }
+}
 
 // Exchange within a quad of lanes (DPP quad_perm): CTRL 0xB1 = lane ^ 1, 0x4E = lane ^ 2.
 template <typename T, int CTRL>
@@ -695,7 +722,8 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
                                                               const int32_t *__restrict__ member,
                                                               const int32_t *__restrict__ gsrc,
                                                               const uint16_t *__restrict__ idx,
-                                                              const T *__restrict__ vals, int64_t n_rows,
+                                                              const T *__restrict__ vals, const int32_t *__restrict__ pat,
+                                                              int64_t n_rows,
                                                               const int32_t *__restrict__ sched, int64_t sched_len,
                                                               const T *__restrict__ X, int64_t ldx, int64_t n_own,
                                                               const T *__restrict__ H, int64_t ldh,
@@ -730,7 +758,10 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
       }
       row[r] = mb >= 0 ? (int64_t)mb * kWellRows + tid : n_rows;
       unsigned px[WMAX];
-      well_load_entries<T, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
+      // (not for 16-byte elements: the second path costs complex128 six spilled registers, and scratch traffic would
+      // sit in the same counter as the DMAs)
+      if (sizeof(T) < 16 && pat) well_load_entries_pat<T, WMAX>(vals, pat, idx, mt.eoff + 8 * r, (sb * R + r) * kWellRows + tid, tid, v[r], px);
+      else well_load_entries<T, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
 #pragma unroll
       for (int t = 0; t < WMAX; t += 2) ixb[r][t / 2] = px[t] | (px[t + 1] << 16);
     }
@@ -1062,7 +1093,8 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
                                                                     const int32_t *__restrict__ member,
                                                                     const int32_t *__restrict__ gsrc,
                                                                     const uint16_t *__restrict__ idx,
-                                                                    const float *__restrict__ vals, int64_t n_rows,
+                                                                    const float *__restrict__ vals,
+                                                                    const int32_t *__restrict__ pat, int64_t n_rows,
                                                                     const int32_t *__restrict__ sched, int64_t sched_len,
                                                                     const unsigned short *__restrict__ Yk, int64_t ldy,
                                                                     int64_t n_own, const unsigned short *__restrict__ H,
@@ -1101,7 +1133,8 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
       }
       row0[r] = mb >= 0 ? (int64_t)mb * kWellRows + (int64_t)wave * 64 : n_rows;
       unsigned px[WMAX];
-      well_load_entries<float, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
+      if (pat) well_load_entries_pat<float, WMAX>(vals, pat, idx, mt.eoff + 8 * r, (sb * R + r) * kWellRows + tid, tid, v[r], px);
+      else well_load_entries<float, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
 #pragma unroll
       for (int t = 0; t < WMAX; t += 2) ixb[r][t / 2] = px[t] | (px[t + 1] << 16);
     }
@@ -1237,6 +1270,7 @@ static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64
   constexpr bool cplx = std::is_same<T, c32>::value || std::is_same<T, c64>::value;
   if (dma) {
     constexpr int EPL = 16 / (int)sizeof(T);
+    const int32_t *pat = sizeof(T) < 16 && env_int("RLH_SPMM_STACK_PAT", 1) != 0 ? h->stk_pat : nullptr;   // the value dictionary, where the handle has one
     const int ld = 5;                                                  // 16-byte pieces per issuing wave and vector (<= 80 pieces)
 #define RLH_STK_DMA(LD_, ...)                                                                                           \
     do {                                                                                                                \
@@ -1248,7 +1282,8 @@ static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64
       }                                                                                                                 \
       hipLaunchKernelGGL((well_stack_dma_kernel<T, kStkR, LD_ __VA_ARGS__>), dim3((unsigned)grid), dim3(1024),          \
                          kStkLdsBytes, c.stream, h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                   \
-                         (const T *)h->stk_vals, h->n_rows, sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m);   \
+                         pat ? (const T *)h->stk_table : (const T *)h->stk_vals, pat, h->n_rows, sched, sched_len, X,   \
+                         ldx, n_own, H, ldh, Y, ldy, (int)m);                                                           \
     } while (0)
     const int dbg = env_int("RLH_SPMM_STACK_DBG", 0);
     RLH_REQUIRE(h->stk_gmax <= 80 * EPL, "rlh_spmm: a stack of %d staging groups", h->stk_gmax);   // (a slot holds 40 or 80 pieces)
@@ -1769,6 +1804,44 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   RLH_HIP(hipMemcpy(h->stk_member, members.data(), members.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   RLH_HIP(hipMalloc((void **)&h->stk_gsrc, (size_t)std::max<int64_t>(goff, 1) * sizeof(int32_t)));
   RLH_HIP(hipMemcpy(h->stk_gsrc, gsrc.data(), (size_t)goff * sizeof(int32_t), hipMemcpyHostToDevice));
+  // value dictionary: the distinct 8-slot value tuples of the rows (byte-wise), given up beyond kStkMaxPatterns
+  {
+    std::vector<int32_t> pat((size_t)nst * R * kWellRows, 0);
+    std::vector<T> table;
+    std::unordered_map<uint64_t, std::vector<int32_t>> seen;
+    bool ok = env_int("RLH_SPMM_STACK_PAT", 1) != 0;
+    for (int64_t sb = 0; sb < nst && ok; ++sb)
+      for (int r = 0; r < R && ok; ++r) {
+        const int64_t eoff = meta[(size_t)sb].eoff + 8 * r;
+        for (int l = 0; l < kWellRows; ++l) {
+          T tup[8];
+          for (int t = 0; t < 8; ++t) tup[t] = vals[(size_t)well_val_index<T>(eoff, t, l)];
+          uint64_t hsh = 1469598103934665603ull;
+          const unsigned char *bytes = reinterpret_cast<const unsigned char *>(tup);
+          for (size_t k = 0; k < sizeof(tup); ++k) hsh = (hsh ^ bytes[k]) * 1099511628211ull;
+          std::vector<int32_t> &cand = seen[hsh];
+          int32_t id = -1;
+          for (int32_t c : cand)
+            if (!memcmp(&table[(size_t)c * 8], tup, sizeof(tup))) { id = c; break; }
+          if (id < 0) {
+            id = (int32_t)(table.size() / 8);
+            if (id >= kStkMaxPatterns) { ok = false; break; }
+            table.insert(table.end(), tup, tup + 8);
+            cand.push_back(id);
+          }
+          pat[(size_t)((sb * R + r) * kWellRows + l)] = id;
+        }
+      }
+    h->stk_npat = 0;
+    if (ok && !table.empty()) {
+      h->stk_npat = (int64_t)table.size() / 8;
+      RLH_HIP(hipMalloc((void **)&h->stk_pat, pat.size() * sizeof(int32_t)));
+      RLH_HIP(hipMemcpy(h->stk_pat, pat.data(), pat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      RLH_HIP(hipMalloc((void **)&h->stk_table, table.size() * sizeof(T)));
+      RLH_HIP(hipMemcpy(h->stk_table, table.data(), table.size() * sizeof(T), hipMemcpyHostToDevice));
+      h->device_bytes += (int64_t)pat.size() * 4 + (int64_t)table.size() * (int64_t)sizeof(T);
+    }
+  }
   RLH_HIP(hipMalloc((void **)&h->stk_idx, ne * sizeof(uint16_t)));
   RLH_HIP(hipMalloc((void **)&h->stk_vals, ne * sizeof(T)));
   RLH_HIP(hipMemcpy(h->stk_idx, idx.data(), ne * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -1852,6 +1925,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->stk_blocks = 0; h->stk_meta = nullptr; h->stk_member = nullptr; h->stk_gsrc = nullptr; h->stk_idx = nullptr;
   h->stk_split_at = -1; h->stk_sched_part[0] = h->stk_sched_part[1] = nullptr; h->stk_sched_part_len[0] = h->stk_sched_part_len[1] = 0;
   h->stk_grid_part[0] = h->stk_grid_part[1] = 0; h->stk_aligned = 0; h->stk_gmax = 0; h->stk_overhang = 0;
+  h->stk_pat = nullptr; h->stk_table = nullptr; h->stk_npat = 0;
   h->stk_vals = nullptr; h->stk_sched = nullptr; h->stk_sched_len = 0; h->stk_grid = 0; h->stk_staged = 0.0; h->well_staged = 0.0;
   h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
   h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
@@ -1923,6 +1997,8 @@ int rlh_csr_destroy(rlh_csr_t h) {
     if (h->stk_gsrc) (void)hipFree(h->stk_gsrc);
     if (h->stk_idx) (void)hipFree(h->stk_idx);
     if (h->stk_vals) (void)hipFree(h->stk_vals);
+    if (h->stk_pat) (void)hipFree(h->stk_pat);
+    if (h->stk_table) (void)hipFree(h->stk_table);
     if (h->stk_sched) (void)hipFree(h->stk_sched);
     for (int k = 0; k < 2; ++k)
       if (h->stk_sched_part[k]) (void)hipFree(h->stk_sched_part[k]);
@@ -2048,6 +2124,7 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
     const int sgrid = part == 0 ? h->stk_grid : h->stk_grid_part[part - 1];
     if (sgrid == 0) return 0;
     constexpr int lds = kBfRingBytes + 16 * kBfOperandBytes;
+    const int32_t *bpat = env_int("RLH_SPMM_STACK_PAT", 1) != 0 ? h->stk_pat : nullptr;
 #define RLH_BF_STACK(VPS_)                                                                                            \
     do {                                                                                                              \
       static bool attr = false;                                                                                       \
@@ -2057,7 +2134,8 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
         attr = true;                                                                                                  \
       }                                                                                                               \
       hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR, VPS_>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, \
-                         h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx, (const float *)h->stk_vals, h->n_rows,  \
+                         h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                                         \
+                         bpat ? (const float *)h->stk_table : (const float *)h->stk_vals, bpat, h->n_rows,            \
                          ssched, ssched_len, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp,     \
                          (float)cb);                                                                                  \
     } while (0)
