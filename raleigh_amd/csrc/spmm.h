@@ -75,7 +75,9 @@ struct rlh_csr {
   // value dictionary of the stacks (constant-coefficient stencils repeat a few dozen rows of values: 27 for the 7-point
   // Laplacian): per row the index of its 8-slot value tuple, and the table of distinct tuples -- 4 bytes per row
   // instead of 8 values; nullptr when the rows have more than kStkMaxPatterns distinct tuples
-  int32_t *stk_pat;        // device, [stack][member][row of the block]
+  int32_t *stk_pat;        // device, [stack][member][row of the block]: value pattern | position pattern << 16
+  uint16_t *stk_dtab;      // device, [stack][member][kStkMaxDeltas][8]: positions minus the row's index in its block, per
+                           // position pattern of that member (a stencil's interior rows all share one); nullptr: none
   void *stk_table;         // device, [pattern][8 values]
   int64_t stk_npat;
   int32_t *stk_sched;      // device

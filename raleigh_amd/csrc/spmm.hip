@@ -229,15 +229,22 @@ __device__ __forceinline__ void well_load_entries(const T *__restrict__ vals, co
 }
 constexpr int kWellRows = 1024;
 constexpr int kStkMaxPatterns = 4096;
+constexpr int kStkMaxDeltas = 64;                  // position patterns per member of a stack
 
 // The same with the values out of the stacks' dictionary: the row's pattern index (4 bytes) and the 8 values of that
 // pattern (a few dozen 16-byte lines that stay in the L1 / L2 for the whole launch) instead of 8 values per row.
+// Positions likewise where the handle has position patterns (dtab): within a member of a stack the staged position of a
+// stencil row's k-th entry is the row's index in the block plus a constant, so the row stores which of the member's
+// few tuples of constants it uses (upper half of its pattern word) instead of 8 positions.
 template <typename T, int WMAX>
 __device__ __forceinline__ void well_load_entries_pat(const T *__restrict__ table, const int32_t *__restrict__ pat,
-                                                      const uint16_t *__restrict__ idx, int64_t eoff, int64_t prow, int tid,
-                                                      T (&v)[WMAX], unsigned (&pos)[WMAX]) {
+                                                      const uint16_t *__restrict__ dtab, const uint16_t *__restrict__ idx,
+                                                      int64_t eoff, int64_t pblock, int tid, T (&v)[WMAX],
+                                                      unsigned (&pos)[WMAX]) {
   constexpr int VPG = 16 / (int)sizeof(T) > 0 ? 16 / (int)sizeof(T) : 1;
-  const int32_t pid = pat[prow];
+  static_assert(WMAX == 8, "one 16-byte piece of positions per row");
+  const unsigned word = (unsigned)pat[pblock * kWellRows + tid];
+  const int32_t pid = (int32_t)(word & 0xffffu);
 #pragma unroll
   for (int g = 0; g < WMAX / VPG; ++g) {
     union { rlh_u32x4e u; T t[VPG]; } piece;
@@ -245,12 +252,15 @@ __device__ __forceinline__ void well_load_entries_pat(const T *__restrict__ tabl
 #pragma unroll
     for (int k = 0; k < VPG; ++k) v[g * VPG + k] = piece.t[k];
   }
+  union { rlh_u32x4e u; unsigned short h[8]; } piece;
+  if (dtab) {
+    piece.u = *reinterpret_cast<const rlh_u32x4e *>(dtab + (pblock * kStkMaxDeltas + (int64_t)(word >> 16)) * 8);
 #pragma unroll
-  for (int g = 0; g < WMAX / 8; ++g) {
-    union { rlh_u32x4e u; unsigned short h[8]; } piece;
-    piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(idx + well_idx_index(eoff, g * 8, tid)));
+    for (int k = 0; k < 8; ++k) pos[k] = ((unsigned)piece.h[k] + (unsigned)tid) & 0xffffu;
+  } else {
+    piece.u = __builtin_nontemporal_load(reinterpret_cast<const rlh_u32x4e *>(idx + well_idx_index(eoff, 0, tid)));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pos[g * 8 + k] = (unsigned)piece.h[k];
+    for (int k = 0; k < 8; ++k) pos[k] = (unsigned)piece.h[k];
   }
 }
 
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
                                                               const int32_t *__restrict__ gsrc,
                                                               const uint16_t *__restrict__ idx,
                                                               const T *__restrict__ vals, const int32_t *__restrict__ pat,
-                                                              int64_t n_rows,
+                                                              const uint16_t *__restrict__ dtab, int64_t n_rows,
                                                               const int32_t *__restrict__ sched, int64_t sched_len,
                                                               const T *__restrict__ X, int64_t ldx, int64_t n_own,
                                                               const T *__restrict__ H, int64_t ldh,
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
       unsigned px[WMAX];
       // (not for 16-byte elements: the second path costs complex128 six spilled registers, and scratch traffic would
       // sit in the same counter as the DMAs)
-      if (sizeof(T) < 16 && pat) well_load_entries_pat<T, WMAX>(vals, pat, idx, mt.eoff + 8 * r, (sb * R + r) * kWellRows + tid, tid, v[r], px);
+      if (sizeof(T) < 16 && pat) well_load_entries_pat<T, WMAX>(vals, pat, dtab, idx, mt.eoff + 8 * r, sb * R + r, tid, v[r], px);
       else well_load_entries<T, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
 #pragma unroll
       for (int t = 0; t < WMAX; t += 2) ixb[r][t / 2] = px[t] | (px[t + 1] << 16);
@@ -1094,7 +1104,8 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
                                                                     const int32_t *__restrict__ gsrc,
                                                                     const uint16_t *__restrict__ idx,
                                                                     const float *__restrict__ vals,
-                                                                    const int32_t *__restrict__ pat, int64_t n_rows,
+                                                                    const int32_t *__restrict__ pat,
+                                                                    const uint16_t *__restrict__ dtab, int64_t n_rows,
                                                                     const int32_t *__restrict__ sched, int64_t sched_len,
                                                                     const unsigned short *__restrict__ Yk, int64_t ldy,
                                                                     int64_t n_own, const unsigned short *__restrict__ H,
@@ -1133,7 +1144,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
       }
       row0[r] = mb >= 0 ? (int64_t)mb * kWellRows + (int64_t)wave * 64 : n_rows;
       unsigned px[WMAX];
-      if (pat) well_load_entries_pat<float, WMAX>(vals, pat, idx, mt.eoff + 8 * r, (sb * R + r) * kWellRows + tid, tid, v[r], px);
+      if (pat) well_load_entries_pat<float, WMAX>(vals, pat, dtab, idx, mt.eoff + 8 * r, sb * R + r, tid, v[r], px);
       else well_load_entries<float, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
 #pragma unroll
       for (int t = 0; t < WMAX; t += 2) ixb[r][t / 2] = px[t] | (px[t + 1] << 16);
@@ -1282,8 +1293,8 @@ static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64
       }                                                                                                                 \
       hipLaunchKernelGGL((well_stack_dma_kernel<T, kStkR, LD_ __VA_ARGS__>), dim3((unsigned)grid), dim3(1024),          \
                          kStkLdsBytes, c.stream, h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                   \
-                         pat ? (const T *)h->stk_table : (const T *)h->stk_vals, pat, h->n_rows, sched, sched_len, X,   \
-                         ldx, n_own, H, ldh, Y, ldy, (int)m);                                                           \
+                         pat ? (const T *)h->stk_table : (const T *)h->stk_vals, pat, pat ? h->stk_dtab : nullptr,      \
+                         h->n_rows, sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m);                           \
     } while (0)
     const int dbg = env_int("RLH_SPMM_STACK_DBG", 0);
     RLH_REQUIRE(h->stk_gmax <= 80 * EPL, "rlh_spmm: a stack of %d staging groups", h->stk_gmax);   // (a slot holds 40 or 80 pieces)
@@ -1832,8 +1843,42 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
           pat[(size_t)((sb * R + r) * kWellRows + l)] = id;
         }
       }
+    // position patterns per member: the positions less the row's index in its block (mod 2^16)
+    std::vector<uint16_t> dtab;
+    bool dok = ok && env_int("RLH_SPMM_STACK_PAT", 1) >= 1 && env_int("RLH_SPMM_STACK_DPAT", 1) != 0;
+    if (dok) {
+      dtab.assign((size_t)nst * R * kStkMaxDeltas * 8, 0);
+      for (int64_t sb = 0; sb < nst && dok; ++sb)
+        for (int r = 0; r < R && dok; ++r) {
+          const int64_t eoff = meta[(size_t)sb].eoff + 8 * r, pb = sb * R + r;
+          uint16_t *tab = dtab.data() + (size_t)pb * kStkMaxDeltas * 8;
+          int used = 0;
+          const int64_t mb = members[(size_t)pb];
+          for (int l = 0; l < kWellRows && dok; ++l) {
+            if (mb < 0 || mb * kWellRows + l >= n) continue;      // no such row: nothing is stored for it, any pattern will do
+            uint16_t tup[8];
+            for (int t = 0; t < 8; ++t) tup[t] = (uint16_t)(idx[(size_t)well_idx_index(eoff, t, l)] - (uint16_t)l);
+            int id = -1;
+            for (int c = used - 1; c >= 0; --c)           // (the last one used is the likeliest)
+              if (!memcmp(tab + c * 8, tup, sizeof(tup))) { id = c; break; }
+            if (id < 0) {
+              if (used >= kStkMaxDeltas) { dok = false; break; }
+              id = used++;
+              memcpy(tab + id * 8, tup, sizeof(tup));
+            }
+            pat[(size_t)(pb * kWellRows + l)] |= id << 16;
+          }
+        }
+      if (!dok)
+        for (int32_t &w : pat) w &= 0xffff;
+    }
     h->stk_npat = 0;
     if (ok && !table.empty()) {
+      if (dok) {
+        RLH_HIP(hipMalloc((void **)&h->stk_dtab, dtab.size() * sizeof(uint16_t)));
+        RLH_HIP(hipMemcpy(h->stk_dtab, dtab.data(), dtab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        h->device_bytes += (int64_t)dtab.size() * 2;
+      }
       h->stk_npat = (int64_t)table.size() / 8;
       RLH_HIP(hipMalloc((void **)&h->stk_pat, pat.size() * sizeof(int32_t)));
       RLH_HIP(hipMemcpy(h->stk_pat, pat.data(), pat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1925,7 +1970,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->stk_blocks = 0; h->stk_meta = nullptr; h->stk_member = nullptr; h->stk_gsrc = nullptr; h->stk_idx = nullptr;
   h->stk_split_at = -1; h->stk_sched_part[0] = h->stk_sched_part[1] = nullptr; h->stk_sched_part_len[0] = h->stk_sched_part_len[1] = 0;
   h->stk_grid_part[0] = h->stk_grid_part[1] = 0; h->stk_aligned = 0; h->stk_gmax = 0; h->stk_overhang = 0;
-  h->stk_pat = nullptr; h->stk_table = nullptr; h->stk_npat = 0;
+  h->stk_pat = nullptr; h->stk_table = nullptr; h->stk_npat = 0; h->stk_dtab = nullptr;
   h->stk_vals = nullptr; h->stk_sched = nullptr; h->stk_sched_len = 0; h->stk_grid = 0; h->stk_staged = 0.0; h->well_staged = 0.0;
   h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
   h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
@@ -1999,6 +2044,7 @@ int rlh_csr_destroy(rlh_csr_t h) {
     if (h->stk_vals) (void)hipFree(h->stk_vals);
     if (h->stk_pat) (void)hipFree(h->stk_pat);
     if (h->stk_table) (void)hipFree(h->stk_table);
+    if (h->stk_dtab) (void)hipFree(h->stk_dtab);
     if (h->stk_sched) (void)hipFree(h->stk_sched);
     for (int k = 0; k < 2; ++k)
       if (h->stk_sched_part[k]) (void)hipFree(h->stk_sched_part[k]);
@@ -2135,7 +2181,8 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
       }                                                                                                               \
       hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR, VPS_>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, \
                          h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                                         \
-                         bpat ? (const float *)h->stk_table : (const float *)h->stk_vals, bpat, h->n_rows,            \
+                         bpat ? (const float *)h->stk_table : (const float *)h->stk_vals, bpat,                       \
+                         bpat ? h->stk_dtab : nullptr, h->n_rows,                                                     \
                          ssched, ssched_len, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp,     \
                          (float)cb);                                                                                  \
     } while (0)

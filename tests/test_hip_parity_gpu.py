@@ -582,7 +582,7 @@ def test_spmm_windowed_schedule_many_blocks(monkeypatch):
 
 @pytest.mark.parametrize('key', KEYS)
 @pytest.mark.parametrize('m', [1, 5, 13, 32])
-@pytest.mark.parametrize('dma,pat', [('2', '1'), ('2', '0'), ('0', '1')])
+@pytest.mark.parametrize('dma,pat', [('2', '1'), ('2', '0'), ('2', 'v'), ('0', '1')])
 def test_spmm_stacked_blocks(monkeypatch, key, m, dma, pat):
     """The stacked windowed layout (two overlapping 1024-row blocks per workgroup, rlh_csr_stacks) forced on matrices
     that are too small to get it by default: 70 x 53 x 31 lap3d has 113 row blocks -- an odd number, so one stack has a
@@ -593,7 +593,10 @@ def test_spmm_stacked_blocks(monkeypatch, key, m, dma, pat):
     monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
     monkeypatch.setenv('RLH_SPMM_STACK', '2')
     monkeypatch.setenv('RLH_SPMM_STACK_DMA', dma)
-    monkeypatch.setenv('RLH_SPMM_STACK_PAT', pat)           # the value dictionary (27 distinct rows of values here) or explicit values
+    # the value dictionary and the position patterns (27 distinct rows of values here), explicit entries ('0'), or the
+    # value dictionary with explicit positions ('v')
+    monkeypatch.setenv('RLH_SPMM_STACK_PAT', '1' if pat == 'v' else pat)
+    monkeypatch.setenv('RLH_SPMM_STACK_DPAT', '0' if pat == 'v' else '1')
     # (complex: grid planes of exactly three row blocks, 111 blocks -- a stack's image must fit one slot of the ring,
     # which the skewed overlap of the other grid's planes and blocks exceeds at 8 and 16 bytes per element)
     A = _sym(lap3d(70, 53, 31, 1.0, 1.01, 1.02) if key in 'sd' else lap3d(64, 48, 37, 1.0, 1.01, 1.02), key)

@@ -59,6 +59,7 @@ for case in range(cases):
     m = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 32, 40]))
     os.environ['RLH_SPMM_STACK_DMA'] = str(rng.choice([0, 1, 2]))
     os.environ['RLH_SPMM_STACK_PAT'] = str(rng.choice([0, 1]))       # the value dictionary (read at create and at launch)
+    os.environ['RLH_SPMM_STACK_DPAT'] = str(rng.choice([0, 1]))      # ... and the position patterns
     op = SparseSymmetricMatrix(A)
     lay = op.layout()
     used['stacks' if lay[3] > 0 else 'none'] += 1
