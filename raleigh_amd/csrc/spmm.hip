@@ -1821,12 +1821,18 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
     std::vector<T> table;
     std::unordered_map<uint64_t, std::vector<int32_t>> seen;
     bool ok = env_int("RLH_SPMM_STACK_PAT", 1) != 0;
+    int32_t last_id = -1;
+    T last_tup[8];
     for (int64_t sb = 0; sb < nst && ok; ++sb)
       for (int r = 0; r < R && ok; ++r) {
         const int64_t eoff = meta[(size_t)sb].eoff + 8 * r;
         for (int l = 0; l < kWellRows; ++l) {
           T tup[8];
           for (int t = 0; t < 8; ++t) tup[t] = vals[(size_t)well_val_index<T>(eoff, t, l)];
+          if (last_id >= 0 && !memcmp(last_tup, tup, sizeof(tup))) {      // (a stencil: the same as the row before)
+            pat[(size_t)((sb * R + r) * kWellRows + l)] = last_id;
+            continue;
+          }
           uint64_t hsh = 1469598103934665603ull;
           const unsigned char *bytes = reinterpret_cast<const unsigned char *>(tup);
           for (size_t k = 0; k < sizeof(tup); ++k) hsh = (hsh ^ bytes[k]) * 1099511628211ull;
@@ -1841,6 +1847,8 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
             cand.push_back(id);
           }
           pat[(size_t)((sb * R + r) * kWellRows + l)] = id;
+          last_id = id;
+          memcpy(last_tup, tup, sizeof(tup));
         }
       }
     // position patterns per member: the positions less the row's index in its block (mod 2^16)
