@@ -1098,7 +1098,8 @@ constexpr int kBfImageBytes = 16 * 1024;           // ng <= 128 groups of 64 two
 constexpr int kBfRingBytes = 64 * 1024;
 constexpr int kBfOperandBytes = 6 * 1024;          // per wave: [member][p, b, y] x 64 lanes x 16 bytes (its first 2 KB double as the tile)
 
-template <int R, int VPS>
+// (DBG: timing-only builds -- 1: no y DMAs, 2: no row products, 4: no operand DMAs / no update: wrong results)
+template <int R, int VPS, int DBG = 0>
 __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMeta *__restrict__ meta,
                                                                     const int32_t *__restrict__ member,
                                                                     const int32_t *__restrict__ gsrc,
@@ -1166,7 +1167,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
     }
     asm volatile("" : "+v"(scol));
     auto issue = [&](int j, unsigned par) {        // the images of vectors j, j + 1 (clamped) into slot `par`
-      if (!mine) return;
+      if (!mine || (DBG & 1)) return;
 #pragma unroll
       for (int u = 0; u < VPS; ++u) {
         const int jv = j + u < m ? j + u : m - 1;
@@ -1188,6 +1189,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
         if (r >= nmem) break;
         const int64_t r8 = row0[r] + rg * 8;
         const int64_t rc = r8 + 8 <= n_rows ? r8 : 0;
+        if constexpr ((DBG & 4) != 0) continue;
         dma16(P + (int64_t)jc * ldp + rc, opbase + (unsigned)(r * 3 + 0) * 1024u);
         dma16(B + (int64_t)jc * ldb + rc, opbase + (unsigned)(r * 3 + 1) * 1024u);
         dma16(Yk + (int64_t)jc * ldy + rc, opbase + (unsigned)(r * 3 + 2) * 1024u);
@@ -1201,7 +1203,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
           for (int r = 0; r < R; ++r) acc[r][jj + u] = 0.f;
         if (jj < cnt) {
           const int j = j0 + jj;
-          if (whole) wait_vm_outstanding(jj == 0 ? 3 * nmem : 0);       // (the previous group's stores: not counted as allowed, see above)
+          if (whole) wait_vm_outstanding(jj == 0 && !(DBG & 4) ? 3 * nmem : 0);       // (the previous group's stores: not counted as allowed, see above)
           else wait_vm_le<0>();
           __builtin_amdgcn_s_barrier();
           const int jn = jj + VPS < cnt ? j + VPS : j0 + 8;          // first vector of the next step
@@ -1214,6 +1216,8 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
             for (int r = 0; r < R; ++r) {
               if (r >= nmem) break;
               float a = 0.f;
+              if constexpr ((DBG & 2) != 0) a = v[r][(jj + u) & 7];
+              else
 #pragma unroll
               for (int t = 0; t < WMAX; t += 2) {
                 unsigned w = ixb[r][t / 2];
@@ -1235,6 +1239,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (r >= nmem) break;
+        if constexpr ((DBG & 4) != 0) { if (acc[r][0] == 1.2345e30f) P[0] = 0; continue; }
         union { rlh_u32x4e u; unsigned short e[8]; } pu, bu, yu, ou;
         pu.u = *reinterpret_cast<const rlh_u32x4e *>(ldsb + opbase + (unsigned)(r * 3 + 0) * 1024u + (unsigned)lane * 16u);
         bu.u = *reinterpret_cast<const rlh_u32x4e *>(ldsb + opbase + (unsigned)(r * 3 + 1) * 1024u + (unsigned)lane * 16u);
@@ -2179,23 +2184,33 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
     if (sgrid == 0) return 0;
     constexpr int lds = kBfRingBytes + 16 * kBfOperandBytes;
     const int32_t *bpat = env_int("RLH_SPMM_STACK_PAT", 1) != 0 ? h->stk_pat : nullptr;
-#define RLH_BF_STACK(VPS_)                                                                                            \
+#define RLH_BF_STACK(VPS_, ...)                                                                                       \
     do {                                                                                                              \
       static bool attr = false;                                                                                       \
       if (!attr) {                                                                                                    \
-        RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&well_stack_cheb_bf16_kernel<kStkR, VPS_>),        \
+        RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&well_stack_cheb_bf16_kernel<kStkR, VPS_ __VA_ARGS__>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                \
         attr = true;                                                                                                  \
       }                                                                                                               \
-      hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR, VPS_>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, \
+      hipLaunchKernelGGL((well_stack_cheb_bf16_kernel<kStkR, VPS_ __VA_ARGS__>), dim3((unsigned)sgrid), dim3(1024), lds, c.stream, \
                          h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                                         \
                          bpat ? (const float *)h->stk_table : (const float *)h->stk_vals, bpat,                       \
                          bpat ? h->stk_dtab : nullptr, h->n_rows,                                                     \
                          ssched, ssched_len, Y, ldy, n_own, H, ldh, P, ldp, B, ldb, (int)m, (float)cy, (float)cp,     \
                          (float)cb);                                                                                  \
     } while (0)
-    if (env_int("RLH_SPMM_BF16_VPS", 2) >= 2) RLH_BF_STACK(2);
-    else RLH_BF_STACK(1);
+    switch (env_int("RLH_SPMM_BF16_DBG", 0)) {
+      case 1: RLH_BF_STACK(2, , 1); break;
+      case 2: RLH_BF_STACK(2, , 2); break;
+      case 3: RLH_BF_STACK(2, , 3); break;
+      case 4: RLH_BF_STACK(2, , 4); break;
+      case 5: RLH_BF_STACK(2, , 5); break;
+      case 6: RLH_BF_STACK(2, , 6); break;
+      case 7: RLH_BF_STACK(2, , 7); break;
+      default:
+        if (env_int("RLH_SPMM_BF16_VPS", 2) >= 2) RLH_BF_STACK(2);
+        else RLH_BF_STACK(1);
+    }
 #undef RLH_BF_STACK
     RLH_HIP(hipGetLastError());
     return 0;
