@@ -1093,7 +1093,8 @@ static int launch_well_w(const rlh_csr *h, int part, int64_t m, const T *X, int6
 //    a DMA issued after them returned with their registers still in flight: NaNs at 215^3, none in the small tests),
 //    and a vmcnt(0) for them would wait for the vectors in flight as well.
 //  * a step's DMAs are issued during the step before, so the only DMAs younger than them are, at the first step of a
-//    group, the group's 3 nmem operand DMAs: that is what the wait allows.
+//    group, the group's 3 nmem operand DMAs (issued in the previous group's epilogue, ahead of its stores): that is what
+//    the wait allows.
 constexpr int kBfImageBytes = 16 * 1024;           // ng <= 128 groups of 64 two-byte elements
 constexpr int kBfRingBytes = 64 * 1024;
 constexpr int kBfOperandBytes = 6 * 1024;          // per wave: [member][p, b, y] x 64 lanes x 16 bytes (its first 2 KB double as the tile)
@@ -1178,12 +1179,11 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
     __builtin_amdgcn_s_barrier();                  // every wave is done with the previous stack's slots
     unsigned par = 0;                              // slot of the step in hand
     issue(0, 0);
-    for (int j0 = 0; j0 < m; j0 += 8) {
-      const int cnt = m - j0 < 8 ? m - j0 : 8;     // vectors of this group
-      // this lane's operands of the update: rows r8 .. r8 + 7 of vector j0 + c8 (clamped where the lane has none)
+    // this lane's operands of the update of the group that starts at vector j0: rows r8 .. r8 + 7 of vector j0 + c8
+    // (clamped where the lane has none), 3 nmem DMAs per wave
+    auto operands = [&](int j0) {
       const int jv = j0 + c8;
       const int jc = jv < m ? jv : m - 1;
-      const bool act = c8 < cnt;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (r >= nmem) break;
@@ -1194,6 +1194,12 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
         dma16(B + (int64_t)jc * ldb + rc, opbase + (unsigned)(r * 3 + 1) * 1024u);
         dma16(Yk + (int64_t)jc * ldy + rc, opbase + (unsigned)(r * 3 + 2) * 1024u);
       }
+    };
+    operands(0);
+    for (int j0 = 0; j0 < m; j0 += 8) {
+      const int cnt = m - j0 < 8 ? m - j0 : 8;     // vectors of this group
+      const int jv = j0 + c8;
+      const bool act = c8 < cnt;
       float acc[R][8];
 #pragma unroll
       for (int jj = 0; jj < 8; jj += VPS) {
@@ -1203,8 +1209,10 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
           for (int r = 0; r < R; ++r) acc[r][jj + u] = 0.f;
         if (jj < cnt) {
           const int j = j0 + jj;
-          if (whole) wait_vm_outstanding(jj == 0 && !(DBG & 4) ? 3 * nmem : 0);       // (the previous group's stores: not counted as allowed, see above)
-          else wait_vm_le<0>();
+          // (a wave that moves no image has nothing to wait for here -- and must not: a wait would make it, and through
+          // the barrier every wave, sit out the acknowledgement of its last stores)
+          if (!whole) wait_vm_le<0>();
+          else if (mine) wait_vm_outstanding(jj == 0 && !(DBG & 4) ? 3 * nmem : 0);
           __builtin_amdgcn_s_barrier();
           const int jn = jj + VPS < cnt ? j + VPS : j0 + 8;          // first vector of the next step
           if (jn < m) issue(jn, par ^ 1u);
@@ -1236,6 +1244,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
       // step only (or this wave issues no vector DMAs)
       if (cnt <= VPS || !mine || !whole) wait_vm_le<0>();
       // the update of this group, member by member; the member's operands first (their area doubles as the tile)
+      rlh_u32x4e outs[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (r >= nmem) break;
@@ -1260,7 +1269,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
 #pragma unroll
           for (int k = 0; k < 8; ++k)
             ou.e[k] = f32_to_bf16(cheb_update(cy, bf16_to_f32(yu.e[k]), cp, bf16_to_f32(pu.e[k]), cb, bf16_to_f32(bu.e[k]), t8[k]));
-          if (act) *reinterpret_cast<rlh_u32x4e *>(P + (int64_t)jv * ldp + r8) = ou.u;
+          outs[r] = ou.u;
         } else if (act && r8 < n_rows) {           // the last rows of the matrix
           unsigned short *pq = P + (int64_t)jv * ldp + r8;
           const unsigned short *bq = B + (int64_t)jv * ldb + r8, *yq = Yk + (int64_t)jv * ldy + r8;
@@ -1268,9 +1277,19 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
             pq[k] = f32_to_bf16(cheb_update(cy, bf16_to_f32(yq[k]), cp, bf16_to_f32(pq[k]), cb, bf16_to_f32(bq[k]), t8[k]));
         }
       }
-      // (the next group's operand DMAs overwrite the area: this wave's reads of it are done -- its own LDS operations
-      // complete in order, and t8 has been consumed by the arithmetic above)
+      // the next group's operands BEFORE this group's stores (this wave's reads of the area are done: its own LDS
+      // operations complete in order, and t8 has been consumed): the stores are then the youngest operations of the wave and
+      // no counted wait ever has to sit out their acknowledgement
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (j0 + 8 < m) operands(j0 + 8);
+      if constexpr ((DBG & 4) == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r >= nmem) break;
+          const int64_t r8 = row0[r] + rg * 8;
+          if ((whole || r8 + 8 <= n_rows) && act) *reinterpret_cast<rlh_u32x4e *>(P + (int64_t)jv * ldp + r8) = outs[r];
+        }
+      }
     }
   }
 }
