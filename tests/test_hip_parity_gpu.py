@@ -673,6 +673,60 @@ def test_spmm_stacked_blocks_with_halo(monkeypatch, key):
     assert cases.rel(Y.data(), y12) < tol
 
 
+@pytest.mark.parametrize('side,stacks,products,steps', [(110, 650, 150, 300), (215, 4853, 100, 1000)])
+def test_stacked_kernels_repeat_bit_for_bit(monkeypatch, side, stacks, products, steps):
+    """The LDS-DMA kernels wait on counted vmcnt values written by hand; a wrong count is a race that shows once in a
+    thousand launches at full size (the first bfloat16 version passed every small test and died of NaNs in the 10^7-row
+    solve: about one bad stack in 5 10^6).  So: many launches on operators with more stacks than CUs -- lap3d 110^3 and
+    the roofline point 215^3 (1000 steps x 4853 stacks) -- every result bit for bit equal to the unstacked kernel's:
+    fp64 products of 32 vectors and chained bfloat16 Chebyshev steps of 16."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.sparse import Bf16Block
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.delenv('RLH_SPMM_STACK', raising=False)
+    A = lap3d(side, side, side, 1.0, 1.01, 1.02)
+    n = A.shape[0]
+    rng = np.random.default_rng(77)
+    op = SparseSymmetricMatrix(A)
+    assert op.layout()[3] == stacks
+    col = rng.standard_normal((1, n))
+    X, Y = Vectors(n, 32), Vectors(n, 32)
+    for j in range(32):
+        X.select(1, j)
+        X.fill(np.roll(col, 11 * j + 1, axis=1) * (1 + 0.01 * j))
+    X.select(32)
+    monkeypatch.setenv('RLH_SPMM_STACK', '0')
+    op.apply(X, Y)
+    want = Y.data()
+    monkeypatch.setenv('RLH_SPMM_STACK', '1')
+    for rep in range(products):
+        op.apply(X, Y)
+        if rep % 25 == 24 or rep < 2:                     # (the launches in between keep the queue full)
+            assert np.array_equal(Y.data(), want), rep
+    del X, Y, want, op
+    op32 = SparseSymmetricMatrix(A.astype(np.float32))
+    m = 16
+    col32 = col.astype(np.float32)
+    y0, p0, b0 = (ops.bf16_round(np.concatenate([np.roll(col32, 7 * j + 3 * k + 1, axis=1) for j in range(m)])) for k in range(3))
+
+    def run(stacked, steps):
+        monkeypatch.setenv('RLH_SPMM_STACK_BF16', '1' if stacked else '0')
+        blocks = []
+        for a in (y0, p0, b0):
+            blk = Bf16Block(n, m)
+            blk.pack(Vectors(a), 1.0)
+            blocks.append(blk)
+        y, p, b = blocks
+        for _ in range(steps):
+            op32.cheb_step_bf16(m, y, p, b, 1.02, -0.25, 2e-6)
+            y, p = p, y
+        out = Vectors(n, m, data_type=np.float32)
+        y.unpack(out)
+        return out.data()
+    got, ref = run(True, steps), run(False, steps)
+    assert np.all(np.isfinite(ref)) and np.array_equal(got, ref)
+
+
 def test_spmm_stacks_only_where_they_pay(monkeypatch):
     """Default policy: no stacks on a small stencil (fewer than four row blocks per CU); stacks of two planes on a large one."""
     from raleigh_amd.algebra.hip import SparseSymmetricMatrix
