@@ -13,17 +13,23 @@ import numpy
 
 from ..algebra.hip import Vectors, SparseSymmetricMatrix
 from ..algebra.hip.host_ops import SparseSymmetricSolver
+from ..algebra.hip.shift_invert import IterativeSymmetricSolver
 from ..core.solver import Problem, Solver, Options, DefaultConvergenceCriteria
 
 
 def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, verb=0, opt=None,
-                 vectors=None, operator=None):
+                 vectors=None, operator=None, solver=None):
     '''Computes several eigenpairs of a sparse real symmetric / Hermitian problem
     (arguments as raleigh/interfaces/partial_hevp.py:23-90).
 
     Extra keywords (multi-GPU): `vectors` -- a factory ``f(n, data_type=)`` returning an
     empty Vectors (e.g. row-sharded), `operator` -- a ready operator for A with
-    ``apply(x, y)``, ``size()`` and ``data_type()`` (e.g. ShardedSparseMatrix).
+    ``apply(x, y)``, ``size()`` and ``data_type()`` (e.g. ShardedSparseMatrix); `solver` -- the
+    shift-invert solver to use instead of the direct factorisation: an IterativeSymmetricSolver
+    (algebra/hip/shift_invert.py: preconditioned block MINRES on the device blocks, for problems whose
+    factors do not fit, and for row-sharded blocks), set up here with A (or `operator`), sigma and B
+    unless it already is.  With an inexact solver the converged pairs get a final Rayleigh-Ritz step
+    with A itself, so that the eigenvalue errors are the square of the eigenvector errors.
 
     Returns (lmd, x, status): eigenvalues ascending, eigenvectors as columns, status as
     in the reference (0 success, 1 iteration limit, 2 no search directions, 3/4 some
@@ -40,10 +46,20 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
             raise RuntimeError('stress stiffness matrix missing in buckling mode')
         opB = None
 
-    if T is None:       # shift-invert through a host factorisation
-        if isinstance(A, SparseSymmetricSolver):
+    inexact = None
+    if T is None:       # shift-invert through a host factorisation (or an iterative solve: `solver`)
+        if isinstance(A, (SparseSymmetricSolver, IterativeSymmetricSolver)):
             solver = A
             n, dtype, sigma = A.size(), A.data_type(), A.sigma()
+            inexact = solver if isinstance(solver, IterativeSymmetricSolver) else None
+        elif solver is not None:
+            inexact = solver
+            if solver.operator() is None:
+                if verb > -1:
+                    print('setting up the iterative linear system solver...')
+                solver.analyse(operator if operator is not None else A, sigma, B)
+                solver.factorize()
+            n, dtype, sigma = solver.size(), solver.data_type(), solver.sigma()
         else:
             m, n = A.shape
             if m != n:
@@ -81,7 +97,10 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
                 print('estimated factorization error: %.1e' % err)
                 print('setup time: %.2e' % (time.time() - start))
         try:
-            neg, pos = solver.inertia()
+            if inexact is not None and vectors is not None:
+                neg, pos = solver.inertia(vectors=lambda n_, nv, data_type: _with(make_vectors(n_, data_type=data_type), nv))
+            else:
+                neg, pos = solver.inertia()
         except RuntimeError as err:
             if verb > -1:
                 print('%s' % err)
@@ -134,12 +153,46 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
     lmd = lmd[ind]
     if verb > -1:
         print('iterations: %d, solve time: %.2e' % (evp_solver.iteration, solve_time))
-    x = eigenvectors.data().T
-    if eigenvectors.nvec() > 0:
-        x = x[:, ind]
     partial_hevp.last = {'iterations': evp_solver.iteration, 'solve_time': solve_time,
                          'residual_norms': evp_solver.residual_norms[ind] if len(ind) else None,
                          'convergence_status': evp_solver.convergence_status[ind] if len(ind) else None,
                          'eigenvector_errors': (evp_solver.eigenvector_errors.kinematic[ind],
                                                 evp_solver.eigenvector_errors.residual[ind]) if len(ind) else None}
+    if inexact is not None:
+        partial_hevp.last.update(inner_solves=inexact.solves, inner_iterations=inexact.iterations,
+                                 inner_columns_applied=inexact.columns_applied)
+    if inexact is not None and not buckling and eigenvectors.nvec() > 0:
+        # (the per-pair records above are those of the iteration, in its order; the refined pairs are a rotation of them)
+        lmd, ind = _refine(eigenvectors, inexact.operator(), opB, lmd)
+    x = eigenvectors.data().T
+    if eigenvectors.nvec() > 0:
+        x = x[:, ind]
     return lmd, x, status
+
+
+def _with(v, nv):
+    """An empty Vectors grown to nv vectors (the factories hand out empty blocks)."""
+    return v.new_vectors(nv)
+
+
+def _refine(x, op_a, op_b, lmd):
+    """Rayleigh-Ritz with A (and B) itself in the span of the converged vectors: the inexact shift-invert
+    operator delivers eigenvectors to its inner tolerance; the Ritz values of the ORIGINAL pencil in their span
+    err by the square of that.  X is rotated in place; returns the eigenvalues (ascending) and the identity
+    order."""
+    import scipy.linalg as sla
+    k = x.nvec()
+    ax = x.new_vectors(k)
+    op_a.apply(x, ax)
+    ga = ax.dot(x)
+    if op_b is None:
+        gb = x.dot(x)
+    else:
+        bx = x.new_vectors(k)
+        op_b.apply(x, bx)
+        gb = bx.dot(x)
+    ga, gb = 0.5 * (ga + ga.conj().T), 0.5 * (gb + gb.conj().T)
+    lam, q = sla.eigh(ga, gb)
+    x.multiply(q.astype(x.data_type()), ax)
+    ax.copy(x)
+    return lam, numpy.arange(k)
