@@ -6,7 +6,8 @@ BASELINE.json), m = 32, fp64, A = 7-point 3-D Laplacian.
 
     python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the rows
+N > 1 runs one rank per GPU under torch.distributed.run (RCCL) -- started by the driver, or, when WORLD_SIZE is not
+set, by this script itself as a child process (`python bench.py --gpus 8` works as typed): the rows
 are sharded over the ranks, every Gram / dots carries one all-reduce, the SpMM
 one halo exchange.  `--scaling strong` (default): the 215^3 rows are split over the N
 ranks -- the north-star's ">= 6x at 8 GPUs at n = 10M" question; `value` is the whole
@@ -198,7 +199,7 @@ def lap_operator(side, dtype, comm, off, nz=None):
                 self.csr.cheb_step_ptr(y.nvec(), y, p, b, cy, cp, cb)
 
             def supports_bf16(self):
-                return dtype == np.float32 and self.csr.layout()[0] == 'well'
+                return self.csr.bf16_ready()
 
             def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
                 self.csr.cheb_step_bf16(m, y, p, b, cy, cp, cb)
@@ -402,6 +403,8 @@ def config_legs(L):
     c5['iteration_runs'] = {str(k): {'seconds': round(v[0], 4), 'iterations': v[1]} for k, v in ts.items() if k != 2}
     c5['iteration_what'] = ('block-JCG driver (raleigh_amd/core/solver.py), block of 64 complex128 vectors, n = 126^3, no preconditioner: '
                             'wall time per iteration from runs of %d and %d iterations' % (ts[4][1], ts[12][1]))
+    del H
+    c5['solve'] = config5_solve(None)
     out['config5'] = c5
     # ---- config 2
     from raleigh_amd.interfaces import pca
@@ -466,6 +469,55 @@ def config_legs(L):
     return out
 
 
+def config5_solve(comm, N=126, below=40, block=64, want=20, degree=16, ratio=250.0):
+    """BASELINE config 5 end to end: Hermitian complex128 operator (lap3d + i skew, n = N^3), block of 64 vectors, the 20
+    eigenpairs nearest a shift with `below` eigenvalues under it, by INEXACT shift-invert (block MINRES with a Chebyshev
+    polynomial preconditioner on the device blocks: raleigh_amd/algebra/hip/shift_invert.py), rows sharded over the ranks
+    when there are several; eigenvalues against the closed-form spectrum.  (A shift in the lower part of the spectrum: for
+    one in the middle of it no polynomial preconditioner exists and no factor fits -- DESIGN.md section 6.)"""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip.shift_invert import IterativeSymmetricSolver
+    from raleigh_amd.synthetic import hermitian_lap3d_rows, hermitian_lap3d_eigenvalues, lap3d_coefficients
+    n, skew = N ** 3, 0.3
+    exact = hermitian_lap3d_eigenvalues(N, N, N, 1.0, 1.01, 1.02, skew=skew)
+    sigma = 0.5 * (exact[below - 1] + exact[below])
+    hi = 4.0 * sum(lap3d_coefficients(N, N, N, 1.0, 1.01, 1.02)) + 2 * skew          # Gershgorin
+    t0 = time.perf_counter()
+    vectors = None
+    if comm is None:
+        from raleigh_amd.algebra.hip import SparseSymmetricMatrix
+        op = SparseSymmetricMatrix(hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n, skew=skew))
+    else:
+        from raleigh_amd.algebra.hip.dist import ShardedSparseMatrix, ShardedVectors, partition
+        off = partition(n, comm.size)
+        r0, r1 = int(off[comm.rank]), int(off[comm.rank + 1])
+        op = ShardedSparseMatrix.from_local_rows(hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, r0, r1, skew=skew), r0, n, comm, off)
+        vectors = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=off)
+    sol = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=degree, ratio=ratio, hi=hi)
+    sol.analyse(op, sigma)
+    sol.factorize()
+    t_setup = time.perf_counter() - t0
+    np.random.seed(1)
+    opt = Options()
+    opt.block_size, opt.max_iter = block, 100
+    t0 = time.perf_counter()
+    lmd, x, status = partial_hevp(sol, which=want, tol=1e-6, verb=-1, opt=opt, vectors=vectors)
+    seconds = time.perf_counter() - t0
+    near = exact[np.argsort(np.abs(exact - sigma))[:want]]
+    err = float(max(np.min(np.abs(lmd - e)) / abs(e) for e in near)) if status == 0 and lmd is not None and len(lmd) >= want else None
+    last = partial_hevp.last
+    return {'problem': 'Hermitian lap3d + i skew, complex128, n = %d^3 = %d, block of %d, the %d eigenpairs nearest sigma = %.4f '
+                       '(%d eigenvalues below it), inexact shift-invert: block MINRES + Chebyshev(degree %d on [hi/%g, hi]), '
+                       'inner tolerance %.0e, eigenvector tolerance 1e-6, Rayleigh-Ritz with A on the converged vectors'
+                       % (N, n, block, want, sigma, below, degree, ratio, sol.tol),
+            'seconds': round(seconds, 3), 'setup_seconds': round(t_setup, 3), 'status': int(status),
+            'negative_eigenvalues_counted': int(sol.inertia()[0]),
+            'outer_iterations': int(last['iterations']), 'inner_solves': int(last['inner_solves']),
+            'inner_iterations': int(last['inner_iterations']), 'operator_applications_in_vectors': int(last['inner_columns_applied']),
+            'max_rel_eigenvalue_error': err}
+
+
 def config4_sharded(L, comm, rows_per_gpu=62500, Nn=40000, r=1280, npc=1000, m=128):
     """BASELINE config 4 on the sharded path: pca of a (rows_per_gpu x world) x 40 000 fp32 matrix, 1000 components, rows
     sharded over the ranks (at 8 GPUs: the 500 000 x 40 000 of BASELINE.json), every shard built in HBM from factors with
@@ -512,6 +564,32 @@ def config4_sharded(L, comm, rows_per_gpu=62500, Nn=40000, r=1280, npc=1000, m=1
             'max_sigma_error_over_sigma_max': float(np.max(np.abs(sv - exact)) / exact[0])}
 
 
+def launch_ranks(n):
+    """Runs this script under torch.distributed.run with n ranks on this node (one per GPU, rendezvous on 127.0.0.1 at a
+    free port) and prints the one JSON line its rank 0 wrote; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    # (the launcher would otherwise pin every rank's host BLAS to ONE thread: the ranks build their operators on the host)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for l in r.stdout.decode(errors='replace').splitlines():
+        if l.startswith('{') and l.rstrip().endswith('}'):
+            line = l
+    if line is not None:
+        sys.stdout.write(line + '\n')
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(r.stdout.decode(errors='replace')[-2000:])
+    return r.returncode if (r.returncode != 0 or line is not None) else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -531,6 +609,11 @@ def main():
     ap.add_argument('--ilu-side', type=int, default=64,
                     help='lap3d side of the GPU-vs-CPU solve with the reference\'s ILU preconditioner (0: skip)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` as the driver types it for N = 1: start the N ranks ourselves -- as a CHILD process,
+        # before anything here has touched the GPU (this process never does) -- and relay rank 0's JSON line and the exit code
+        sys.exit(launch_ranks(args.gpus))
 
     # Everything any library prints (RCCL prints a version banner on stdout) goes to stderr;
     # the real stdout carries exactly one JSON line, written at the very end by rank 0.
@@ -764,6 +847,10 @@ def main():
             ok = guarded('config4', lambda: config4_sharded(L, comm, rows_per_gpu=192, Nn=96, r=24, npc=8, m=8)) and ok
         else:
             ok = guarded('config4', lambda: config4_sharded(L, comm)) and ok
+        if rehearsal:
+            ok = guarded('config5', lambda: config5_solve(comm, N=8, below=6, block=16, want=6, degree=6, ratio=20.0)) and ok
+        else:
+            ok = guarded('config5', lambda: config5_solve(comm)) and ok
     if world == 1 and comm is None:
         if args.ilu_side > 0:
             ok = guarded('solve_ilu', lambda: solve_ilu_pair(args.ilu_side)) and ok

@@ -206,6 +206,13 @@ int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per
  * stacks (3.42 / 2.42 for the 7-point stencil on 215^3).  rlh_spmm on the whole operator uses the stacks when they exist;
  * RLH_SPMM_STACK=0 in the environment (create or call time) turns them off, =2 at create time builds them regardless. */
 int rlh_csr_stacks(rlh_csr_t h, int64_t *stacks, double *staged_per_row, double *staged_per_row_stacked);
+/* Whether rlh_spmm_cheb_bf16_part would take this operator: *ok = 1 if it is a float32 operator in the 1024-row windowed
+ * layout whose staging groups all lie inside the column range and -- with a halo block (n_own < the column count: a row
+ * shard) of leading dimension ldh -- n_own and ldh are multiples of 8 and the groups start on multiples of 8 columns, so
+ * that the 2-byte staging stays on 16-byte pieces.  The layout conditions depend on the SHARD, so ranks of one row-sharded
+ * operator can differ: callers agree on the answer (all-reduce MIN) BEFORE the first halo exchange of a bfloat16 step,
+ * never by catching the launch's error afterwards. */
+int rlh_csr_bf16_ready(rlh_csr_t h, int64_t n_own, int64_t ldh, int *ok);
 /* Columns [0, n_own) are read from X, columns [n_own, n_cols) from the halo block
  * H (row c - n_own), which holds the off-shard rows received from other ranks;
  * single GPU: n_own = n_cols, H = NULL. */

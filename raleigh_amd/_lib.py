@@ -68,6 +68,7 @@ SIGNATURES = {
                      ctypes.POINTER(_i64)],
     'rlh_csr_layout': [_p, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)],
     'rlh_csr_stacks': [_p, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+    'rlh_csr_bf16_ready': [_p, _i64, _i64, ctypes.POINTER(_int)],
     'rlh_spmm': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64],
     'rlh_spmm_cheb': [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.c_double, ctypes.c_double,
                       ctypes.c_double],

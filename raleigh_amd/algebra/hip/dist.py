@@ -384,6 +384,7 @@ class ShardedSparseMatrix:
                 dbuf.copy_(comm.torch.from_numpy(idx.view(np.uint8)))
                 self._send.append((p, dbuf, int(idx.size)))
         self._bufs = {}
+        self._bf16 = None
 
     def size(self):
         return self._n
@@ -480,7 +481,17 @@ class ShardedSparseMatrix:
         self._op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), halo_ptr, ldh, part=2)
 
     def supports_bf16(self):
-        return self._dtype == np.float32 and self._op.layout()[0] == 'well'
+        """Whether EVERY rank's shard takes the bfloat16 Chebyshev step: the layout conditions (staging groups inside the
+        column range and on multiples of 8 columns, halo block on 16-byte rows) depend on the shard, so the ranks agree on
+        the answer once (all-reduce MIN) -- a rank that found out by a failed launch would already have posted its 2-byte
+        halo messages, and would restart with 4-byte ones while its peers went on."""
+        if self._bf16 is None:
+            c = self._comm
+            mine = 1 if self._op.bf16_ready(self._ld_halo) else 0
+            t = c.torch.tensor([mine], dtype=c.torch.int32, device=c.device)
+            c.dist.all_reduce(t, op=c.dist.ReduceOp.MIN, group=c.group)
+            self._bf16 = bool(int(t.item()))
+        return self._bf16
 
     def cheb_step_bf16(self, m, y, p, b, cy, cp, cb):
         """The fused step on bfloat16 work blocks (sparse.Bf16Block) of the local rows: the halo rows

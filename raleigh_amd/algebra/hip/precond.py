@@ -209,8 +209,10 @@ class ChebyshevPreconditioner:
                 self._apply_bf16(x, y, m)
                 return
             except _lib.RlhError as e:
-                # (a shard whose halo layout the 2-byte staging cannot take: the same polynomial on float32 work blocks)
-                if 'rlh_spmm_cheb_bf16' not in str(e):
+                # An unsharded operator whose layout the 2-byte staging cannot take after all: the same polynomial on
+                # float32 work blocks.  On a row-sharded operator the error is final: supports_bf16() above is agreed on
+                # by all ranks BEFORE any exchange is posted, and a rank falling back alone would break the exchange.
+                if 'rlh_spmm_cheb_bf16' not in str(e) or hasattr(x, 'comm'):
                     raise
                 import warnings
                 warnings.warn('bfloat16 work blocks refused by the operator (%s): float32 work blocks instead' % e)

@@ -24,6 +24,8 @@ reach the host (two reductions per step), as in the eigensolver itself.
 import numpy as np
 import scipy.linalg as sla
 
+from ...core.solver import _single_threaded_blas
+
 
 class ShiftedOperator:
     """y = (A - sigma B) x on device blocks (B None: identity)."""
@@ -81,9 +83,13 @@ class MinresInfo:
         LOWER bound on the number of negative eigenvalues of K, reached as soon as the block Krylov space holds
         the negative invariant subspace (extreme, well separated eigenvalues of the preconditioned operator: a
         few steps of a block of that many vectors).  The three-term recurrence loses orthogonality once a Ritz
-        pair has converged and T_k then carries further copies of it; as in Cullum & Willoughby's test the copies
-        are told from the genuine value by their weight in the FIRST block (the start vectors' share of the Ritz
-        vector): ~1e-18 against >= 1e-2 for a random start, so only Ritz values weighing more than 1e-10 count."""
+        pair has converged, and T_k then carries further copies of it.  The copies are told from genuine values
+        by the FIRST-block rows of the Ritz vectors (the start block's coordinates of each Ritz vector, the
+        quantity Cullum & Willoughby's test looks at): copies of one eigenvector have parallel rows -- or rows
+        of weight ~1e-18 -- while distinct eigenvectors, multiple eigenvalues included, have independent ones
+        for a random start block.  The count is therefore the numerical RANK of those rows over all negative
+        Ritz values, which cannot exceed the width of the start block: a count that reaches the width says the
+        probe was too narrow (IterativeSymmetricSolver.inertia widens it)."""
         sizes = [a.shape[0] for a in alphas]
         off = np.concatenate(([0], np.cumsum(sizes)))
         t = np.zeros((off[-1], off[-1]), dtype=alphas[0].dtype)
@@ -94,9 +100,11 @@ class MinresInfo:
                 t[off[j + 1]:off[j + 2], off[j]:off[j + 1]] = bt
                 t[off[j]:off[j + 1], off[j + 1]:off[j + 2]] = bt.conj().T
         lam, vec = sla.eigh(t)
-        neg = lam < 0
-        weight = np.sum(np.abs(vec[:sizes[0], neg]) ** 2, axis=0)
-        self.negative = int(np.sum(weight > 1e-10))
+        first = vec[:sizes[0], lam < 0]
+        self.negative_ritz = int(first.shape[1])
+        sv = np.linalg.svd(first, compute_uv=False) if first.size else np.zeros((0,))
+        self.negative = int(np.sum(sv > 1e-3 * sv[0])) if sv.size else 0
+        self.probe_width = int(sizes[0])
 
 
 def block_minres(op, b, x, precond=None, tol=1e-8, max_iter=500, work=None, drop=1e-7, count_negative=False):
@@ -105,6 +113,12 @@ def block_minres(op, b, x, precond=None, tol=1e-8, max_iter=500, work=None, drop
     with apply(u, w) or None; tol: per-column bound on ||r||_M / ||b||_M (a scalar or one value per column).
     work: a dict that keeps the work blocks between calls; count_negative: also count the negative eigenvalues
     of the projected operator (MinresInfo.negative).  Returns a MinresInfo."""
+    # (the m x m LAPACK / BLAS work is latency-bound: on a many-core host the thread pool costs 10x its serial time)
+    with _single_threaded_blas():
+        return _block_minres(op, b, x, precond, tol, max_iter, work, drop, count_negative)
+
+
+def _block_minres(op, b, x, precond, tol, max_iter, work, drop, count_negative):
     m = b.nvec()
     info = MinresInfo()
     if m < 1:
@@ -245,13 +259,16 @@ class IterativeSymmetricSolver:
     [hi / ratio, hi], hi the Gershgorin bound or `hi=`): the right choice for a shift in the lower part of the
     spectrum of a positive definite A, where A - sigma I has few negative eigenvalues and p(A)(A - sigma I)
     is a cluster at 1 plus the few hundred eigenvalues below hi / ratio, which the block Krylov space absorbs.
-    tol: bound on the relative residual (in the preconditioner's norm) of every column."""
+    tol: bound on the relative residual (in the preconditioner's norm) of every column; None: 1e-10, or, inside
+    partial_hevp, a hundredth of the eigenvector tolerance asked for there (within [1e-12, 1e-6]) -- the images
+    A X of the iterates are carried by recurrence, so what the solves leave behind is never corrected later and
+    bounds the accuracy of the eigenvectors: 1e-4 stalls a 1e-6 eigensolve, 1e-6 costs it nothing."""
 
-    def __init__(self, dtype=np.float64, pos_def=False, tol=1e-10, max_iter=1000, preconditioner='auto', degree=16,
+    def __init__(self, dtype=np.float64, pos_def=False, tol=None, max_iter=1000, preconditioner='auto', degree=16,
                  ratio=250.0, hi=None):
         self._dtype = np.dtype(dtype).type
         self._pos_def = bool(pos_def)
-        self.tol = float(tol)
+        self.tol = None if tol is None else float(tol)
         self.max_iter = int(max_iter)
         self._pre_spec = ('chebyshev' if pos_def else None) if isinstance(preconditioner, str) and preconditioner == 'auto' \
             else preconditioner
@@ -291,18 +308,21 @@ class IterativeSymmetricSolver:
             raise ValueError('unknown preconditioner %s' % repr(spec))
         if not self._pos_def:
             raise ValueError("the 'chebyshev' preconditioner needs a positive definite matrix (pos_def=True)")
+        import scipy.sparse as scs
         from .precond import ChebyshevPreconditioner, gershgorin_upper_bound
         hi = self._hi
         if hi is None:
             if self._matrix is None:
                 raise ValueError('hi= (an upper bound of the spectrum) is needed with a ready operator')
-            import scipy.sparse as scs
             u = scs.triu(scs.csr_matrix(self._matrix), format='csr')
             hi = gershgorin_upper_bound(u + scs.triu(u, 1).conj().T)
         self._pre = ChebyshevPreconditioner(self._opa, hi, ratio=self._ratio, degree=self._degree)
 
+    def _tol(self):
+        return 1e-10 if self.tol is None else self.tol
+
     def solve(self, b, x, tol=None):
-        info = block_minres(self._op, b, x, precond=self._pre, tol=self.tol if tol is None else tol,
+        info = block_minres(self._op, b, x, precond=self._pre, tol=self._tol() if tol is None else tol,
                             max_iter=self.max_iter, work=self._work)
         self.solves += 1
         self.iterations += info.iterations
@@ -310,7 +330,7 @@ class IterativeSymmetricSolver:
         self.last = info
         if not info.converged:
             raise RuntimeError('block MINRES did not reach %.1e in %d steps (worst column %.1e): move the shift or '
-                               'strengthen the preconditioner' % (self.tol, info.iterations, float(np.max(info.residuals))))
+                               'strengthen the preconditioner' % (self._tol(), info.iterations, float(np.max(info.residuals))))
 
     def apply(self, b, x):
         self.solve(b, x)
@@ -325,12 +345,17 @@ class IterativeSymmetricSolver:
             from .vectors import Vectors
             k = 32 if probe is None else int(probe)
             make = vectors if vectors is not None else (lambda n, nv, data_type: Vectors(n, nv, data_type=data_type))
-            b, x = make(self._n, k, data_type=self._dtype), make(self._n, k, data_type=self._dtype)
-            b.fill_random()
-            info = block_minres(self._op, b, x, precond=self._pre, tol=self.tol, max_iter=self.max_iter,
-                                count_negative=True)
-            if not info.converged:
-                raise RuntimeError('block MINRES probe did not converge: inertia unavailable')
+            while True:
+                k = min(k, self._n)
+                b, x = make(self._n, k, data_type=self._dtype), make(self._n, k, data_type=self._dtype)
+                b.fill_random()
+                info = block_minres(self._op, b, x, precond=self._pre, tol=self._tol(), max_iter=self.max_iter,
+                                    count_negative=True)
+                if not info.converged:
+                    raise RuntimeError('block MINRES probe did not converge: inertia unavailable')
+                if info.negative < info.probe_width or k >= self._n:
+                    break
+                k *= 2                      # as many negative eigenvalues as start vectors: the count is saturated
             self._neg = info.negative
         return self._neg, int(self._n - self._neg)
 

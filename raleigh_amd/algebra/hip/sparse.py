@@ -32,7 +32,11 @@ class CsrOperator:
 
     def __init__(self, csr, n_own=None, upper=False):
         csr = scs.csr_matrix(csr)
-        csr.sort_indices()
+        if not csr.has_canonical_format:
+            # an assembled matrix may carry duplicate or unsorted entries: a COPY is put into canonical form (equal
+            # columns summed, indices sorted) -- the caller's own object is never modified
+            csr = csr.copy()
+            csr.sum_duplicates()
         dt = csr.data.dtype.type
         if dt not in _lib.DTYPE_CODE:
             raise ValueError('unsupported data type')
@@ -88,6 +92,13 @@ class CsrOperator:
         n, a, b = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         _lib.check(_lib.lib().rlh_csr_stacks(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
         return int(n.value), float(a.value), float(b.value)
+
+    def bf16_ready(self, ldh=0):
+        """Whether the bfloat16 Chebyshev step takes this operator (rlh_csr_bf16_ready); ldh: the leading dimension of
+        the halo block of a row shard (ignored without halo columns)."""
+        ok = ctypes.c_int()
+        _lib.check(_lib.lib().rlh_csr_bf16_ready(self._h, self._n_own, int(ldh), ctypes.byref(ok)))
+        return bool(ok.value)
 
     def apply_ptr(self, m, x_ptr, ldx, y_ptr, ldy, halo_ptr=None, ldh=0, part=0):
         """part 0: all rows; 1: the rows that need no halo column; 2: the others (rlh_spmm_part)."""
@@ -175,7 +186,7 @@ class SparseSymmetricMatrix:
         self.__op.cheb_step_bf16(m, y, p, b, cy, cp, cb)
 
     def supports_bf16(self):
-        return self.__op.data_type() == np.float32 and self.__op.layout()[0] == 'well'
+        return self.__op.bf16_ready()
 
     def layout(self):
         """Device layout of the operator and its stacked row blocks (diagnostics: CsrOperator.layout, .stacks)."""

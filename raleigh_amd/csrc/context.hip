@@ -39,6 +39,9 @@ int check_async_error() {
   Context &c = ctx();
   if (c.async_err_h && *(volatile unsigned *)c.async_err_h != 0) {
     set_error("a device kernel gave up waiting for a dependency (persistent triangular solve): its results are invalid");
+    // reported once, to the call that synchronised behind the failed launch: the caller can rebuild the operator or fall
+    // back, and the library stays usable (the word used to stay set until rlh_finalize)
+    *(volatile unsigned *)c.async_err_h = 0;
     return 1;
   }
   return 0;

@@ -2097,6 +2097,14 @@ int rlh_csr_info(rlh_csr_t h, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, in
   return 0;
 }
 
+}  // extern "C"
+// the layout conditions of the bfloat16 Chebyshev step: ONE definition for the launch and for rlh_csr_bf16_ready
+static inline bool bf16_layout_ok(const rlh_csr *h) { return h->dtype == RLH_S && h->well_blocks > 0 && h->well_inbounds; }
+static inline bool bf16_halo_ok(const rlh_csr *h, int64_t n_own, int64_t ldh) {
+  return h->well_aligned && n_own % 8 == 0 && ldh % 8 == 0;
+}
+extern "C" {
+
 int rlh_csr_layout(rlh_csr_t h, int *layout, int64_t *stored, double *staged_per_slot) {
   RLH_REQUIRE(h != nullptr, "rlh_csr_layout: null handle");
   if (layout) *layout = h->wide_blocks > 0 ? 2 : (h->well_blocks > 0 ? 1 : 0);
@@ -2110,6 +2118,12 @@ int rlh_csr_stacks(rlh_csr_t h, int64_t *stacks, double *staged_per_row, double 
   if (stacks) *stacks = h->stk_blocks;
   if (staged_per_row) *staged_per_row = h->well_staged;
   if (staged_per_row_stacked) *staged_per_row_stacked = h->stk_staged;
+  return 0;
+}
+
+int rlh_csr_bf16_ready(rlh_csr_t h, int64_t n_own, int64_t ldh, int *ok) {
+  RLH_REQUIRE(h != nullptr && ok != nullptr, "rlh_csr_bf16_ready: null argument");
+  *ok = bf16_layout_ok(h) && h->n_rows <= n_own && n_own <= h->n_cols && (n_own == h->n_cols || bf16_halo_ok(h, n_own, ldh));
   return 0;
 }
 
@@ -2175,11 +2189,11 @@ int rlh_spmm_cheb_bf16_part(rlh_csr_t h, int part, int64_t m, const void *Y16, i
   RLH_REQUIRE(part >= 0 && part <= 2, "rlh_spmm_cheb_bf16: part must be 0 (all rows), 1 (interior) or 2 (boundary)");
   RLH_REQUIRE(m >= 0, "rlh_spmm_cheb_bf16: negative block size");
   if (m == 0 || h->n_rows == 0) return 0;
-  RLH_REQUIRE(h->dtype == RLH_S && h->well_blocks > 0 && h->well_inbounds,
+  RLH_REQUIRE(bf16_layout_ok(h),
               "rlh_spmm_cheb_bf16: needs a float32 operator in the 1024-row windowed layout (rows of at most 8 "
               "entries) with every staging group inside the column range");
   RLH_REQUIRE(h->n_rows <= n_own && n_own <= h->n_cols, "rlh_spmm_cheb_bf16: the operator block must be square in its own rows");
-  RLH_REQUIRE(n_own == h->n_cols || (H16 && h->well_aligned && n_own % 8 == 0 && ldh % 8 == 0 && ((uintptr_t)H16 % 16) == 0),
+  RLH_REQUIRE(n_own == h->n_cols || (H16 && bf16_halo_ok(h, n_own, ldh) && ((uintptr_t)H16 % 16) == 0),
               "rlh_spmm_cheb_bf16: a halo block needs n_own and ldh to be multiples of 8, a 16-byte aligned block "
               "and staging groups on multiples of 8 columns");
   RLH_REQUIRE(Y16 && P16 && B16 && P16 != Y16 && P16 != B16, "rlh_spmm_cheb_bf16: bad block pointers");

@@ -296,6 +296,14 @@ struct Watch {                                  // bounds every spin of one thre
     }
     return dead;
   }
+  // a wait has ended with what it waited for: the limit bounds ONE wait without progress, not the whole launch (a launch
+  // serialised by a profiler's counter collection, a GPU shared with another job or a very long chain may legitimately
+  // run for longer than any fixed bound).  Only a thread that has spun long enough to have looked at the clock pays
+  // for reading it again.
+  __device__ __forceinline__ void progress() {
+    if (spins > 255u) t0 = (unsigned long long)wall_clock64();
+    spins = 0u;
+  }
 };
 
 // which group does XCD `xcc` solve in its round `round`?  The first of its workgroups to ask takes the next
@@ -317,6 +325,7 @@ __device__ __forceinline__ int claim_group(unsigned *ctrl, unsigned xcc, int rou
     if (watch.expired()) return -1;
     v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  watch.progress();
   const int g = (int)v - 2;
   return g < ngroups ? g : -1;
 }
@@ -350,14 +359,40 @@ __device__ __forceinline__ Batch<T> load_batch(const int32_t *__restrict__ cols,
 
 // L1-bypassing loads of those of four pieces whose bit is set in `want`, one wait (every load is an L2 request of its
 // own -- a workgroup's gathers queue at its CU's one request per clock -- so neither padding slots nor pieces that
-// have arrived are asked for again)
+// have arrived are asked for again).  The four predicated loads AND their wait are ONE asm statement with the
+// destinations as read-write operands: the compiler does not track loads issued from asm, so between a load in one
+// statement and its wait in another it would be free to copy or spill a destination register -- reading it before the
+// data has landed (piece_ready() would then judge stale data).  Lanes whose bit is clear keep what they held: the
+// predication is the EXEC mask, saved and restored around each load.
 __device__ __forceinline__ void loadm_sc1(unsigned want, const u32x4 *p0, const u32x4 *p1, const u32x4 *p2, const u32x4 *p3, u32x4 &x0,
                                           u32x4 &x1, u32x4 &x2, u32x4 &x3) {
-  if (want & 1u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x0) : "v"(p0) : "memory");
-  if (want & 2u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x1) : "v"(p1) : "memory");
-  if (want & 4u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x2) : "v"(p2) : "memory");
-  if (want & 8u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x3) : "v"(p3) : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "memory");
+  unsigned long long saved;
+  unsigned bit;
+  asm volatile(
+      "v_and_b32 %5, 1, %6\n\t"
+      "v_cmp_ne_u32 vcc, 0, %5\n\t"
+      "s_and_saveexec_b64 %4, vcc\n\t"
+      "global_load_dwordx4 %0, %7, off sc1\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "v_and_b32 %5, 2, %6\n\t"
+      "v_cmp_ne_u32 vcc, 0, %5\n\t"
+      "s_and_saveexec_b64 %4, vcc\n\t"
+      "global_load_dwordx4 %1, %8, off sc1\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "v_and_b32 %5, 4, %6\n\t"
+      "v_cmp_ne_u32 vcc, 0, %5\n\t"
+      "s_and_saveexec_b64 %4, vcc\n\t"
+      "global_load_dwordx4 %2, %9, off sc1\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "v_and_b32 %5, 8, %6\n\t"
+      "v_cmp_ne_u32 vcc, 0, %5\n\t"
+      "s_and_saveexec_b64 %4, vcc\n\t"
+      "global_load_dwordx4 %3, %10, off sc1\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&s"(saved), "=&v"(bit)
+      : "v"(want), "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory", "vcc");
 }
 
 // acc -= sum over this lane's entries [e, end) (stride sl) of value * (X or, from end_x on, R)[column]; `cur` holds the
@@ -373,6 +408,7 @@ __device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T>
     const u32x4 *p0 = ((cur.rhs & 1u) ? R : X) + (int64_t)cur.c[0] * ppt + pp, *p1 = ((cur.rhs & 2u) ? R : X) + (int64_t)cur.c[1] * ppt + pp;
     const u32x4 *p2 = ((cur.rhs & 4u) ? R : X) + (int64_t)cur.c[2] * ppt + pp, *p3 = ((cur.rhs & 8u) ? R : X) + (int64_t)cur.c[3] * ppt + pp;
     typename PieceOf<T>::U x0, x1, x2, x3;
+    x0.w = x1.w = x2.w = x3.w = u32x4{0u, 0u, 0u, 0u};      // (read-write operands of loadm_sc1: a defined value)
     unsigned want = (1u << cnt) - 1u;
     for (;;) {
       loadm_sc1(want, p0, p1, p2, p3, x0.w, x1.w, x2.w, x3.w);
@@ -380,7 +416,8 @@ __device__ __forceinline__ void accumulate(typename PieceOf<T>::U &acc, Batch<T>
       if ((want & 2u) && piece_ready<T>(x1.w)) want &= ~2u;
       if ((want & 4u) && piece_ready<T>(x2.w)) want &= ~4u;
       if ((want & 8u) && piece_ready<T>(x3.w)) want &= ~8u;
-      if (want == 0u || watch.expired()) break;
+      if (want == 0u) { watch.progress(); break; }
+      if (watch.expired()) break;
       if (nap == 1) __builtin_amdgcn_s_sleep(1); else if (nap == 2) __builtin_amdgcn_s_sleep(2); else if (nap >= 4) __builtin_amdgcn_s_sleep(4);
     }
 #pragma unroll

@@ -38,19 +38,16 @@ _DEVICE_EIGH_MIN = 768
 
 
 def _eigh(a, single=False):
-    """Eigenpairs (ascending) of a Hermitian k x k matrix.  The k x k problems are the cost of an update once k reaches
-    the thousands (k = 1400: 0.36-0.41 s per call with LAPACK on the GPU box's host cores, against 0.05 s for all the
-    dense products of the update), so from k = 768 on the matrix goes to the vendor's dense eigensolver on the GPU
-    through PyTorch (torch.linalg.eigh: 0.033 s at k = 1400, 0.08 s at 2800 -- what the reference hands to LAPACK,
-    raleigh/interfaces/lra.py:216-222, on the device the data lives on) -- in a process that has PyTorch imported
-    already (a row-sharded run, or the caller did): a cold `import torch` costs ~10 s on a fresh box, more than it saves
-    in one call; RLH_DEVICE_EIGH=2 imports it regardless, =0 never uses it.  Otherwise, or without a GPU in PyTorch:
-    LAPACK on the host, as before -- in single precision if `single` (single-precision data, k >= 256: the rotation is
-    applied to single-precision blocks anyway, and it halves the host time; on the device double costs the same as
-    single and the vendor's single-precision solver orders close eigenvalues less reliably)."""
+    """Eigenpairs (ascending) of a Hermitian k x k matrix: LAPACK on the host (BASELINE's north star keeps the small
+    eigenproblems there), in single precision if `single` (single-precision data, k >= 256: the rotation is applied to
+    single-precision blocks anyway, and it halves the host time).  The k x k problems are the cost of a PCA update once k
+    reaches the thousands (k = 1400: 0.36-0.41 s per call on the GPU box's host cores against 0.05 s for all the dense
+    products of the update); RLH_DEVICE_EIGH=1 in the environment -- an explicit choice, never the state of
+    sys.modules -- hands matrices of k >= 768 to the vendor's dense eigensolver on the GPU through PyTorch instead
+    (0.033 s at k = 1400); any failure there (PyTorch missing, no memory next to a 10 GB shard, no solver library)
+    falls back to LAPACK."""
     k = a.shape[0]
-    mode = os.environ.get('RLH_DEVICE_EIGH', '1')
-    if k >= _DEVICE_EIGH_MIN and mode != '0' and (mode == '2' or 'torch' in sys.modules):
+    if k >= _DEVICE_EIGH_MIN and os.environ.get('RLH_DEVICE_EIGH', '0') == '1':
         try:
             import torch
             if torch.cuda.is_available():
@@ -58,7 +55,7 @@ def _eigh(a, single=False):
                 dev = torch.device('cuda', _lib.device() or 0)
                 lam, w = torch.linalg.eigh(torch.from_numpy(numpy.ascontiguousarray(a)).to(dev))
                 return lam.cpu().numpy(), w.cpu().numpy()
-        except ImportError:
+        except (ImportError, RuntimeError):
             pass
     if single:
         a = a.astype(numpy.complex64 if numpy.iscomplexobj(a) else numpy.float32)

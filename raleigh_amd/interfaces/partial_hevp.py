@@ -96,6 +96,8 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
             if verb > -1:
                 print('estimated factorization error: %.1e' % err)
                 print('setup time: %.2e' % (time.time() - start))
+        if inexact is not None and inexact.tol is None:
+            inexact.tol = min(1e-6, max(1e-12, 0.01 * tol))
         try:
             if inexact is not None and vectors is not None:
                 neg, pos = solver.inertia(vectors=lambda n_, nv, data_type: _with(make_vectors(n_, data_type=data_type), nv))

@@ -66,6 +66,12 @@ class _OperatorSVD:
         self._coef = None
         if (mean is not None or deflate is not None) and not (self._fused and shift):
             raise ValueError('a given mean / a deflated operator need a Matrix with apply_r1 and shift')
+        if mean is not None and not getattr(self.op, 'r1_transposed', True):
+            # with a GIVEN mean e^T z != 0, so y = A_s^H z needs the rank-one term in the TRANSPOSED product, which a
+            # row-sharded matrix does not fold in: said here, at construction, not in the middle of a solve with
+            # collectives in flight
+            raise ValueError('a given mean needs a Matrix that takes a rank-one term in the transposed product '
+                             '(a row-sharded matrix does not)')
         if shift:
             dt = self.op.data_type()
             self.ones = self.op.new_vectors(m, 1)

@@ -145,6 +145,20 @@ def main():
     assert status == 0, status
     assert np.max(np.abs(lmd4[:4] - ana) / ana) < 1e-10
     assert fake_lib_calls().get('spmm_cheb_bf16', 0) > 10
+    # ONE rank's shard cannot take the 2-byte staging: all ranks learn it from supports_bf16() -- an all-reduce
+    # MIN of the library's own layout test -- BEFORE any exchange is posted, and all of them run the float32 work blocks;
+    # decided per rank by a failed launch, the refusing rank would restart with 4-byte halo messages against its peers' 2-byte ones
+    from raleigh_amd import _lib
+    op32b = ShardedSparseMatrix(A.astype(np.float32), comm)
+    _lib.library().bf16_refused = (rank == size - 1)
+    assert op32b.supports_bf16() is False
+    _lib.library().bf16_refused = False
+    before = fake_lib_calls().get('spmm_cheb_bf16', 0)
+    np.random.seed(1)
+    T = ChebyshevPreconditioner(None, gershgorin_upper_bound(A), ratio=100, degree=6, low_precision_op=op32b, storage='bf16')
+    lmd4b, x4b, status = partial_hevp(None, T=T, which=4, tol=1e-8, verb=-1, opt=opt, vectors=mk, operator=op)
+    assert status == 0 and np.max(np.abs(lmd4b[:4] - ana) / ana) < 1e-10
+    assert fake_lib_calls().get('spmm_cheb_bf16', 0) == before                  # nobody took the bfloat16 step
 
     # shift-invert on row-sharded vectors (BASELINE config 5's layout): the factors are replicated, the block is
     # gathered on every rank's device (all_gather), solved by the triangular chain there, and no host solve runs
@@ -165,6 +179,22 @@ def main():
     assert fake_lib_calls().get('rlh_sptrsv_solve_chain', 0) > calls_before + 3      # the device chain did the solves
     r5 = A5 @ x5 - x5 * lmd5
     assert np.max(np.linalg.norm(r5, axis=0)) < 1e-6 * np.abs(exact5).max()
+
+    # the same problem by INEXACT shift-invert (block MINRES on the row-sharded operator: every reduction one all-reduce of
+    # an m x m matrix, the operator exchanging its halo, nothing replicated, nothing gathered): BASELINE config 5's path
+    from raleigh_amd.algebra.hip.shift_invert import IterativeSymmetricSolver
+    op5 = ShardedSparseMatrix(A5, comm)
+    mk5 = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm)
+    sol5 = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=6, ratio=20.0, hi=gershgorin_upper_bound(A5))
+    calls_before = fake_lib_calls().get('rlh_sptrsv_solve_chain', 0)
+    np.random.seed(1)
+    lmd6, x6, status = partial_hevp(None, sigma=sigma5, which=(3, 3), tol=1e-7, verb=-1, vectors=mk5, operator=op5, solver=sol5)
+    assert status == 0, status
+    assert np.max(np.abs(np.sort(lmd6) - want5)) < 1e-10 * np.abs(exact5).max()
+    assert fake_lib_calls().get('rlh_sptrsv_solve_chain', 0) == calls_before                  # no factors anywhere
+    assert sol5.inertia() == (21, n5 - 21) and sol5.solves > 2
+    r6 = A5 @ x6 - x6 * lmd6
+    assert np.max(np.linalg.norm(r6, axis=0)) < 1e-6 * np.abs(exact5).max()
 
     # row-sharded dense operator and PCA (BASELINE config 4 layout): same answer as one rank
     from raleigh_amd.algebra.hip.dist import ShardedDenseMatrix, ShardedAMatrix

@@ -58,6 +58,7 @@ class FakeLib:
         self._next_handle = 1
         self.calls = {}
         self.initialised = None
+        self.bf16_refused = False          # (tests: a shard whose layout the bfloat16 staging cannot take)
 
     def _count(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1
@@ -437,6 +438,12 @@ class FakeLib:
         ctypes.cast(layout, ctypes.POINTER(ctypes.c_int))[0] = 1
         ctypes.cast(stored, ctypes.POINTER(ctypes.c_int64))[0] = 0
         ctypes.cast(ratio, ctypes.POINTER(ctypes.c_double))[0] = 0.0
+        return 0
+
+    def rlh_csr_bf16_ready(self, h, n_own, ldh, ok):
+        c = self._csr[_addr(h)]
+        good = c.code == 0 and (n_own == c.mat.shape[1] or (n_own % 8 == 0 and ldh % 8 == 0)) and not self.bf16_refused
+        ctypes.cast(ok, ctypes.POINTER(ctypes.c_int))[0] = 1 if good else 0
         return 0
 
     def rlh_csr_stacks(self, h, stacks, a, b):

@@ -12,17 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_two_rank_bench_line():
-    env = dict(os.environ, RLH_BENCH_REHEARSAL='1', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29583',
-               OMP_NUM_THREADS='2')
+    """Exactly `python bench.py --gpus 2 ...` with no rank environment set: the script starts its own two ranks under
+    torch.distributed.run (as a child process) and relays rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(RLH_BENCH_REHEARSAL='1', OMP_NUM_THREADS='2')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--side', '12', '--solve-side', '12']
-    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, cwd=ROOT) for r in (0, 1)]
-    outs = [p.communicate(timeout=600) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:].decode() + outs[1][1][-2000:].decode()
-    assert outs[1][0].strip() == b''                       # only rank 0 prints
-    lines = [l for l in outs[0][0].decode().splitlines() if l.strip()]
-    assert len(lines) == 1
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:].decode()
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1                                 # only rank 0's line reaches stdout
     d = json.loads(lines[0])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
@@ -34,4 +33,7 @@ def test_two_rank_bench_line():
     c4 = d['config4']                                      # the row-sharded PCA leg (toy size under the rehearsal)
     assert 'error' not in c4 and c4['max_sigma_error_over_sigma_max'] < 5e-3 and c4['iterations'] > 0
     assert d['solve']['status'] == 0 and d['solve']['max_rel_eigenvalue_error'] < 1e-9
+    c5 = d['config5']                                      # the row-sharded inexact shift-invert leg (toy size)
+    assert 'error' not in c5 and c5['status'] == 0 and c5['max_rel_eigenvalue_error'] < 1e-10
+    assert c5['negative_eigenvalues_counted'] == 6 and c5['inner_iterations'] > c5['inner_solves'] > 2
     assert 'cpu_baseline' not in d and 'configs' not in d  # N = 1 only

@@ -143,6 +143,35 @@ def test_config5_complex_hermitian_block64_shift_invert():
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-6 * np.max(np.abs(exact))
 
 
+def test_config5_full_size_inexact_shift_invert():
+    """BASELINE config 5 end to end AT ITS SIZE on one GPU: n = 126^3 = 2 000 376, complex128, block of 64, the 20 eigenpairs
+    nearest a shift with 40 eigenvalues below it, by inexact shift-invert (block MINRES + Chebyshev polynomial on the device
+    blocks; no factorisation exists at this size): eigenvalues against the closed-form spectrum to 1e-10, the Lanczos inertia
+    count exact, residuals of the returned pairs small."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip.shift_invert import IterativeSymmetricSolver
+    from raleigh_amd.synthetic import hermitian_lap3d_rows, hermitian_lap3d_eigenvalues
+    N, below = 126, 40
+    n = N ** 3
+    H = hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n)
+    exact = hermitian_lap3d_eigenvalues(N, N, N, 1.0, 1.01, 1.02)
+    sigma = 0.5 * (exact[below - 1] + exact[below])
+    opt = Options()
+    opt.block_size = 64
+    np.random.seed(1)
+    sol = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=16, ratio=250.0)
+    lmd, x, status = partial_hevp(H, sigma=sigma, which=20, tol=1e-6, verb=-1, opt=opt, solver=sol)
+    assert status == 0 and len(lmd) >= 20
+    assert sol.inertia() == (below, n - below)
+    for e in exact[np.argsort(np.abs(exact - sigma))[:20]]:
+        assert np.min(np.abs(lmd - e)) < 1e-10 * abs(e)
+    keep = np.argsort(np.abs(lmd - sigma))[:20]
+    r = H @ x[:, keep] - x[:, keep] * lmd[keep]
+    assert np.max(np.linalg.norm(r, axis=0)) < 1e-6 * np.max(np.abs(exact))
+    assert partial_hevp.last['iterations'] < 20 and sol.iterations < 400
+
+
 def test_config5_full_size_block64_operations():
     """Config 5 at its full size on one GPU (n = 126^3 = 2 000 376 rows, complex128, m = 64: blocks of
     2.05 GB): the operations of one solver iteration checked through size-independent properties --

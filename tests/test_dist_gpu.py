@@ -161,3 +161,32 @@ def test_sharded_shift_invert_stays_on_the_device(comm):
     assert status == 0
     want = np.sort(exact[37:45])
     assert np.max(np.abs(np.sort(lmd) - want)) < 1e-10 * np.abs(exact).max()
+
+
+def test_config5_sharded_inexact_shift_invert_at_full_size(comm):
+    """BASELINE config 5's own layout at its own size with the collectives forced: row-sharded complex128 blocks of 64 at
+    n = 126^3, the sharded operator (halo exchange with itself), every reduction of the eigensolver AND of the block MINRES
+    inside it through RCCL, nothing gathered and nothing factorised; 20 eigenvalues nearest the shift to 1e-10."""
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix, partition
+    from raleigh_amd.algebra.hip.shift_invert import IterativeSymmetricSolver
+    from raleigh_amd.synthetic import hermitian_lap3d_rows, hermitian_lap3d_eigenvalues, lap3d_coefficients
+    N, below = 126, 40
+    n = N ** 3
+    exact = hermitian_lap3d_eigenvalues(N, N, N, 1.0, 1.01, 1.02)
+    sigma = 0.5 * (exact[below - 1] + exact[below])
+    off = partition(n, comm.size)
+    comm.forced_halo_rows = 2 * N * N
+    op = ShardedSparseMatrix.from_local_rows(hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n), 0, n, comm, off)
+    hi = 4.0 * sum(lap3d_coefficients(N, N, N, 1.0, 1.01, 1.02)) + 0.6
+    sol = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=16, ratio=250.0, hi=hi)
+    opt = Options()
+    opt.block_size = 64
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(None, sigma=sigma, which=20, tol=1e-6, verb=-1, opt=opt, solver=sol, operator=op,
+                                  vectors=lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=off))
+    assert status == 0 and len(lmd) >= 20
+    assert sol.inertia()[0] == below
+    for e in exact[np.argsort(np.abs(exact - sigma))[:20]]:
+        assert np.min(np.abs(lmd - e)) < 1e-10 * abs(e)

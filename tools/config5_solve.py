@@ -14,6 +14,7 @@ from raleigh_amd.synthetic import hermitian_lap3d_rows, hermitian_lap3d_eigenval
 arg = lambda i, d, t=float: t(sys.argv[i]) if len(sys.argv) > i else d
 N, K, degree, ratio = arg(1, 126, int), arg(2, 40, int), arg(3, 16, int), arg(4, 250.0)
 itol, otol = arg(5, 1e-10), arg(6, 1e-6)
+low = arg(7, 0, int)
 t0 = time.time()
 H = hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, N ** 3)
 exact = hermitian_lap3d_eigenvalues(N, N, N, 1.0, 1.01, 1.02)
