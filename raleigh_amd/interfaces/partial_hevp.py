@@ -130,7 +130,11 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
         n = opA.size()
         dtype = numpy.dtype(opA.data_type()).type
         eigenvectors = make_vectors(n, data_type=dtype)
-        evp = Problem(eigenvectors, opA) if B is None else Problem(eigenvectors, opA, opB, 'gen')
+        # A x = lambda B x, as the reference's docstring says (partial_hevp.py:32-36).  The reference itself passes the string
+        # 'gen' as Problem's `prod` argument here (partial_hevp.py:214), which makes the type 'pro' (solver.py:240-249): its
+        # preconditioned generalized mode returns the eigenvalues of A B x = lambda x (tests/golden/known_answers.json:
+        # hevp_gen_lap10_ilu5_reference_returns_AB).  The documented problem is solved here.
+        evp = Problem(eigenvectors, opA) if B is None else Problem(eigenvectors, opA, opB)
         evp_solver = Solver(evp)
         if T is not True:          # T=True: no preconditioner (identity), blocks never leave the GPU
             evp_solver.set_preconditioner(T)

@@ -72,6 +72,47 @@ def hermitian_lap3d_eigenvalues(nx, ny, nz, ax, ay, az, skew=0.3):
     return np.sort((ex[:, None, None] + ey[None, :, None] + ez[None, None, :]).ravel())
 
 
+def mass_matrix(nx, ny, nz):
+    """A symmetric positive definite "mass" matrix on the nx x ny x nz grid of lap3d: the Kronecker product of the 1-D
+    linear finite-element mass matrices tridiag(1/6, 2/3, 1/6) (27-point stencil): the B of the generalized problems
+    A x = lambda B x of raleigh/interfaces/partial_hevp.py:103-200 in the tests."""
+    def m1(k):
+        return sp.diags([np.full(k - 1, 1.0 / 6), np.full(k, 2.0 / 3), np.full(k - 1, 1.0 / 6)], [-1, 0, 1], format='csr')
+    b = sp.kron(m1(nz), sp.kron(m1(ny), m1(nx)), format='csr')
+    b.sort_indices()
+    return b
+
+
+def stress_stiffness(nx, ny, nz, ax, ay, az, ratio=0.3):
+    """A symmetric INDEFINITE "stress stiffness" matrix Ks on the grid of lap3d for the buckling problems
+    (K + alpha Ks) v = 0 (raleigh/examples/buckling_evp.py): Ks = -(Dx - ratio Dy), Dx / Dy the second differences along x / y
+    alone (compression along x, tension along y).  With K = lap3d(nx, ny, nz, ax, ay, az) everything commutes, so the load
+    factors are known in closed form (`buckling_load_factors`)."""
+    cx, cy, cz = lap3d_coefficients(nx, ny, nz, ax, ay, az)
+
+    def d1(k, c):
+        return sp.diags([np.full(k - 1, -c), np.full(k, 2 * c), np.full(k - 1, -c)], [-1, 0, 1], format='csr')
+    ex, ey, ez = sp.identity(nx, format='csr'), sp.identity(ny, format='csr'), sp.identity(nz, format='csr')
+    dx = sp.kron(ez, sp.kron(ey, d1(nx, cx)), format='csr')
+    dy = sp.kron(ez, sp.kron(d1(ny, cy), ex), format='csr')
+    ks = sp.csr_matrix(-(dx - ratio * dy))
+    ks.sort_indices()
+    return ks
+
+
+def buckling_load_factors(nx, ny, nz, ax, ay, az, ratio=0.3):
+    """All load factors alpha of (lap3d + alpha stress_stiffness) v = 0, positive ones ascending first: mode (i, j, k) has
+    alpha = (lx_i + ly_j + lz_k) / (lx_i - ratio ly_j), l the eigenvalues of the 1-D second differences."""
+    cx, cy, cz = lap3d_coefficients(nx, ny, nz, ax, ay, az)
+    lx = 2 * cx * (1 - np.cos(np.arange(1, nx + 1) * np.pi / (nx + 1)))
+    ly = 2 * cy * (1 - np.cos(np.arange(1, ny + 1) * np.pi / (ny + 1)))
+    lz = 2 * cz * (1 - np.cos(np.arange(1, nz + 1) * np.pi / (nz + 1)))
+    num = lx[:, None, None] + ly[None, :, None] + lz[None, None, :]
+    den = (lx[:, None, None] - ratio * ly[None, :, None]) + 0 * lz[None, None, :]
+    alpha = (num / den).ravel()
+    return np.sort(alpha[alpha > 0]), np.sort(alpha[alpha < 0])[::-1]
+
+
 def _hash01(i, j):
     """Deterministic pseudo-random numbers in [0, 1) from two int64 arrays (splitmix64 finaliser)."""
     z = (i.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (j.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F))

@@ -263,6 +263,72 @@ def solver_known_answers():
     return res
 
 
+def generalized_known_answers():
+    """The reference's partial_hevp on generalized and buckling problems (raleigh/interfaces/partial_hevp.py:103-244,
+    raleigh/core/solver.py:224-260 'gen' / 'pro'): A = lap3d(10, 9, 8), B the Kronecker finite-element mass matrix, Ks an
+    indefinite stress stiffness matrix (raleigh_amd/synthetic.py builds B and Ks for this script and for the tests alike).
+    MKL backend (PARDISO factorisation, ILUT preconditioner)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from raleigh_amd.synthetic import mass_matrix, stress_stiffness
+    from raleigh.interfaces.partial_hevp import partial_hevp
+    res = {}
+    nx, ny, nz = 10, 9, 8
+    A = lap3d(nx, ny, nz, 1.0, 1.01, 1.02)
+    B = mass_matrix(nx, ny, nz)
+    dense = sla.eigh(A.toarray(), B.toarray(), eigvals_only=True)
+    # 'gen': preconditioned iterations on A x = lambda B x.  The reference's partial_hevp hands the string 'gen' to
+    # Problem's fourth argument `prod` (partial_hevp.py:214), and any non-None `prod` makes the problem type 'pro'
+    # (solver.py:240-249): what it returns are the eigenvalues of A B x = lambda x, not of A x = lambda B x as its
+    # docstring says.  Both are recorded: the core solver driven with Problem(v, A, B) -- the generalized problem proper,
+    # the known answer of this repository's partial_hevp -- and partial_hevp's own output with what it is.
+    from raleigh.algebra.dense_cblas import Vectors as MVectors
+    from raleigh.algebra.sparse_mkl import Operator
+    T = IncompleteLU(A)
+    T.factorize()
+    np.random.seed(1)
+    v = MVectors(A.shape[0], data_type=np.float64)
+    solver = Solver(Problem(v, SparseSymmetricMatrix(A), SparseSymmetricMatrix(B)))
+    solver.set_preconditioner(Operator(T))
+    opt = Options()
+    opt.convergence_criteria = DefaultConvergenceCriteria()
+    opt.convergence_criteria.set_error_tolerance('k eigenvector error', 1e-8)
+    opt.verbosity = -1
+    status = solver.solve(v, opt, which=(5, 0))
+    lmd = np.sort(solver.eigenvalues)
+    x = v.data().T[:, np.argsort(solver.eigenvalues)]
+    r = A @ x - (B @ x) * lmd
+    res['core_gen_lap10_ilu5'] = {'status': int(status), 'iterations': int(solver.iteration), 'eigenvalues': lmd.tolist(),
+                                  'dense': dense[:len(lmd)].tolist(), 'residual_norms': np.linalg.norm(r, axis=0).tolist()}
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(A, B=B, T=T, which=5, tol=1e-8, verb=-1, opt=Options())
+    chol = np.linalg.cholesky(B.toarray())
+    res['hevp_gen_lap10_ilu5_reference_returns_AB'] = {
+        'status': int(status), 'eigenvalues': lmd.tolist(),
+        'dense_of_A_B': np.linalg.eigvalsh(chol.T @ A.toarray() @ chol)[:5].tolist(),
+        'note': "the reference passes 'gen' as Problem's `prod` argument: these are eigenvalues of A B x = lambda x"}
+    # 'pro': shift-invert (A - sigma B)^-1 B, eigenvalues on both sides of an interior shift, and nearest-to-sigma
+    sigma = 0.5 * (dense[7] + dense[8])
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(A, B=B, sigma=sigma, which=(3, 4), tol=1e-8, verb=-1, opt=Options())
+    res['hevp_pro_lap10_si34'] = {'status': int(status), 'sigma': float(sigma), 'eigenvalues': lmd.tolist(),
+                                  'dense': dense[5:12].tolist()}
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(A, B=B, sigma=sigma, which=6, tol=1e-8, verb=-1, opt=Options())
+    res['hevp_pro_lap10_si6'] = {'status': int(status), 'sigma': float(sigma), 'eigenvalues': lmd.tolist()}
+    # buckling: (K + alpha Ks) v = 0 (partial_hevp returns -alpha, largest first).  Load factor shift 1.06: three load factors
+    # lie below it, so which = 5 becomes (3, 2) and which = 2 becomes (3, 0) (partial_hevp.py:183-187: never fewer than all
+    # the load factors below the shift); shift 1.0: none below, which = 3 becomes (0, 3)
+    Ks = stress_stiffness(nx, ny, nz, 1.0, 1.01, 1.02)
+    for name, sigma, which in (('hevp_buckling_lap10_5', -1.06, 5), ('hevp_buckling_lap10_2', -1.06, 2),
+                               ('hevp_buckling_lap10_3_shift1', -1.0, 3)):
+        np.random.seed(1)
+        lmd, x, status = partial_hevp(A, B=Ks, buckling=True, sigma=sigma, which=which, tol=1e-8, verb=-1, opt=Options())
+        r = A @ x - (Ks @ x) * lmd
+        res[name] = {'status': int(status), 'sigma': sigma, 'which': which, 'eigenvalues': lmd.tolist(),
+                     'residual_norms': np.linalg.norm(r, axis=0).tolist()}
+    return res
+
+
 def pca_known_answers():
     from raleigh.examples.pca.generate_matrix import generate
     from raleigh.interfaces.pca import pca, pca_error
@@ -340,13 +406,16 @@ def truncated_svd_known_answers():
 
 
 def main():
-    if '--pca-update-only' in sys.argv or '--truncated-svd-only' in sys.argv:   # adds entries to the existing file
+    only = [a for a in ('--pca-update-only', '--truncated-svd-only', '--generalized-only') if a in sys.argv]
+    if only:                                     # adds entries to the existing file
         path = os.path.join(HERE, 'known_answers.json')
         known = json.load(open(path))
-        known.update(pca_update_known_answers() if '--pca-update-only' in sys.argv else truncated_svd_known_answers())
+        known.update({'--pca-update-only': pca_update_known_answers, '--truncated-svd-only': truncated_svd_known_answers,
+                      '--generalized-only': generalized_known_answers}[only[0]]())
         with open(path, 'w') as f:
             json.dump(known, f, indent=1)
-        print(json.dumps({k: v for k, v in known.items() if 'update' in k or 'incremental' in k or 'tsvd' in k}, indent=1)[-3000:])
+        print(json.dumps({k: v for k, v in known.items() if 'gen_' in k
+                          or 'pro_' in k or 'buckling' in k}, indent=1)[-4000:])
         return
     shapes = [(5, 257), (16, 192)]
     for key in DTYPES:
@@ -373,6 +442,8 @@ def main():
     known.update(pca_known_answers())
     known.update(pca_update_known_answers())
     known.update(truncated_svd_known_answers())
+    if HAVE_MKL:
+        known.update(generalized_known_answers())
     known['_meta'] = {'numpy': np.__version__, 'have_mkl': HAVE_MKL,
                       'reference': 'evgueni-ovtchinnikov/raleigh v1.3.5 @ 2024-12-20'}
     with open(os.path.join(HERE, 'known_answers.json'), 'w') as f:
