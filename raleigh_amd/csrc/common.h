@@ -6,7 +6,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "rlhip.h"
 
@@ -29,6 +33,25 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
       return 1;                       \
     }                                 \
   } while (0)
+
+// ---------------------------------------------------------------- environment, host thread pool
+static inline int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+// threads for the host-side set-up work (ILUT factorisation, SpMM layout build): RLH_HOST_THREADS, else the machine's
+// hardware threads, at most 16 (a GPU box hands every GPU's process about that share of its cores)
+int host_threads();
+// f(t, nthreads) on min(want, host_threads()) threads (the calling thread is one of them)
+template <typename F> static inline void host_parallel(int want, F f) {
+  int t = host_threads();
+  if (t > want) t = want;
+  if (t <= 1) { f(0, 1); return; }
+  std::vector<std::thread> pool;
+  for (int i = 1; i < t; ++i) pool.emplace_back([&f, i, t]() { f(i, t); });
+  f(0, t);
+  for (auto &th : pool) th.join();
+}
 
 // ---------------------------------------------------------------- dtypes
 struct c32 { float re, im; };

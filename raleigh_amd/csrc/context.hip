@@ -22,6 +22,15 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   return (int)e ? (int)e : 1;
 }
 
+int host_threads() {
+  int t = env_int("RLH_HOST_THREADS", 0);
+  if (t <= 0) {
+    t = (int)std::thread::hardware_concurrency();
+    if (t > 16) t = 16;
+  }
+  return t < 1 ? 1 : t;
+}
+
 Context &ctx() {
   static Context c;
   return c;

@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -106,11 +108,6 @@ struct rlh_csr {
 };
 
 namespace rlh {
-
-static inline int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
 
 template <typename T>
 struct ChebArgs {
@@ -228,11 +225,22 @@ static inline void fill_group_sources(const std::vector<Win> &ws, int32_t ngroup
   for (; filled < ngroups; ++filled) gsrc[filled] = last;
 }
 
+// RLH_SPMM_VERBOSE=1: wall time of the phases of a layout build on stderr
+struct PhaseClock {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseClock() : on(env_int("RLH_SPMM_VERBOSE", 0) != 0), t(std::chrono::steady_clock::now()) {}
+  void lap(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "csr layout: %-34s %.3f s\n", what, std::chrono::duration<double>(now - t).count());
+    t = now;
+  }
+};
+
 template <typename F>
 static void parallel_blocks(int64_t nblocks, F fn) {
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt < 1) nt = 1;
-  if (nt > 16) nt = 16;
+  unsigned nt = (unsigned)host_threads();
   if ((int64_t)nt > nblocks) nt = (unsigned)(nblocks > 0 ? nblocks : 1);
   std::atomic<int64_t> next(0);
   auto worker = [&]() {

@@ -1570,6 +1570,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   const int64_t nblocks = (n + kWellRows - 1) / kWellRows;
   h->well_blocks = 0;
   if (nblocks == 0 || h->nnz == 0) return 0;
+  PhaseClock clk;
   std::vector<std::vector<Win>> wins((size_t)nblocks);
   std::vector<int32_t> width((size_t)nblocks, 0), ngroups((size_t)nblocks, 0);
   parallel_blocks(nblocks, [&](int64_t b) {
@@ -1580,6 +1581,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     // groups per block: a multiple of 8 (one 16-byte load covers 2, 4 or -- bfloat16 -- 8 groups)
     ngroups[b] = find_windows(indptr, indices, r0, r1, h->n_cols, 32, 64, 8, wins[b]) / 64;
   });
+  clk.lap("well: windows");
   int32_t wmax = 0, gmax = 0;
   int64_t staged = 0, slots = 0;
   for (int64_t b = 0; b < nblocks; ++b) {
@@ -1635,6 +1637,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
       }
     }
   });
+  clk.lap("well: entries");
   // what the 16-byte staging path may assume
   h->well_inbounds = 1;
   h->well_aligned = 1;
@@ -1645,6 +1648,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   std::vector<int32_t> sched;
   well_schedule(wins, nblocks, n, kWellRows, ctx().num_cu, h->well_order);
   well_layout(h->well_order, ctx().num_cu, sched, h->well_grid);
+  clk.lap("well: schedule");
   h->well_maxcol.resize((size_t)nblocks);
   for (int64_t b = 0; b < nblocks; ++b) h->well_maxcol[(size_t)b] = wins[b].back().start + wins[b].back().len - 1;
   h->well_sched_len = (int64_t)sched.size();
@@ -1663,6 +1667,7 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   h->device_bytes = nblocks * (int64_t)sizeof(WellMeta) + (int64_t)sched.size() * 4 + goff * 4 + (int64_t)ne * (2 + (int64_t)sizeof(T));
   h->well_blocks = nblocks;
   h->well_staged = (double)staged / (double)n;
+  clk.lap("well: upload");
   if (h->well_inbounds) return stack_build<DT>(h, indptr, indices, values_, wins, staged);
   return 0;
 }
@@ -1686,6 +1691,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   // (fewer than 4 row blocks per CU: halving the number of work units costs more than the staging saves -- lap3d 61^3,
   // 222 blocks: 12.4 us as blocks, 14.1 us as stacks)
   if (mode == 0 || nblocks < 2 || (mode < 2 && nblocks < 4 * (int64_t)ctx().num_cu)) return 0;
+  PhaseClock clk;
   // overlap of block b's windows with the rows of block c, both directions summed
   std::vector<std::vector<std::pair<int32_t, int64_t>>> adj((size_t)nblocks);
   auto bump = [&](int64_t b, int64_t c, int64_t ov) {
@@ -1746,7 +1752,9 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       ngroups[(size_t)sb] = find_windows_of(cols, nc8, 32, 64, 8, swins[(size_t)sb]) / 64;
     });
   };
+  clk.lap("stack: matching");
   analyse(nst);
+  clk.lap("stack: windows");
   // a stack whose image does not fit (grid planes half a row block out of step with the blocks: 126^2 rows = 15.5
   // blocks) is taken apart into stacks of one
   bool split = false;
@@ -1816,6 +1824,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       }
     }
   });
+ clk.lap("stack: entries");
   h->stk_overhang = 0;
   for (int64_t g = 0; g < goff; ++g) {
     if ((int64_t)gsrc[(size_t)g] + 64 > nc8) return 0;                  // 16-byte staging needs whole groups
@@ -1830,6 +1839,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   std::vector<int32_t> sched;
   well_schedule(swins, nst, n, kWellRows, ctx().num_cu, order, &owner);
   well_layout(order, ctx().num_cu, sched, h->stk_grid);
+  clk.lap("stack: schedule");
   h->stk_sched_len = (int64_t)sched.size();
   RLH_HIP(hipMalloc((void **)&h->stk_sched, sched.size() * sizeof(int32_t)));
   RLH_HIP(hipMemcpy(h->stk_sched, sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1875,6 +1885,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
           memcpy(last_tup, tup, sizeof(tup));
         }
       }
+    clk.lap("stack: value dictionary");
     // position patterns per member: the positions less the row's index in its block (mod 2^16)
     std::vector<uint16_t> dtab;
     bool dok = ok && env_int("RLH_SPMM_STACK_PAT", 1) >= 1 && env_int("RLH_SPMM_STACK_DPAT", 1) != 0;
@@ -1904,6 +1915,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       if (!dok)
         for (int32_t &w : pat) w &= 0xffff;
     }
+    clk.lap("stack: position dictionary");
     h->stk_npat = 0;
     if (ok && !table.empty()) {
       if (dok) {
@@ -1926,6 +1938,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   h->device_bytes += nst * (int64_t)sizeof(WellMeta) + (int64_t)sched.size() * 4 + goff * 4 + (int64_t)members.size() * 4 +
                      (int64_t)ne * (2 + (int64_t)sizeof(T));
   h->stk_blocks = nst;
+  clk.lap("stack: upload");
   return 0;
 }
 
@@ -1940,35 +1953,74 @@ template <> inline c64 conj_of(c64 v) { return c64{v.re, -v.im}; }
 
 template <typename T>
 static int csr_from_upper(rlh_csr_t *out, int dtype, int64_t n, const int64_t *indptr, const int32_t *indices, const T *values) {
-  std::vector<int64_t> rp((size_t)n + 1, 0), below((size_t)n, 0);
-  for (int64_t i = 0; i < n; ++i) {
-    int32_t prev = -1;
-    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
-      const int32_t j = indices[e];
-      RLH_REQUIRE(j >= 0 && j < n, "rlh_csr_create_upper: column index %d out of range in row %lld", j, (long long)i);
-      RLH_REQUIRE(j > prev, "rlh_csr_create_upper: the column indices of row %lld are not sorted", (long long)i);
-      prev = j;
-      if (j < i) continue;
-      ++rp[(size_t)i + 1];
-      if (j > i) { ++rp[(size_t)j + 1]; ++below[(size_t)j]; }
+  PhaseClock clk;
+  // counting pass, rows dealt to the host threads: own entries per row, mirrored entries per target row (atomic: two
+  // threads may mirror into the same row)
+  std::unique_ptr<std::atomic<int64_t>[]> cnt(new std::atomic<int64_t>[(size_t)n + 1]);
+  std::vector<int64_t> below((size_t)n, 0);
+  std::atomic<int64_t> bad_row{-1};
+  std::atomic<int> bad_kind{0};
+  host_parallel(64, [&](int t, int nt) {
+    for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) cnt[(size_t)i + 1].store(0, std::memory_order_relaxed);
+    if (t == 0) cnt[0].store(0, std::memory_order_relaxed);
+  });
+  host_parallel(64, [&](int t, int nt) {
+    for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+      int32_t prev = -1;
+      int64_t own = 0;
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (j < 0 || j >= n) { bad_row.store(i); bad_kind.store(1); return; }
+        if (j <= prev) { bad_row.store(i); bad_kind.store(2); return; }
+        prev = j;
+        if (j < i) continue;
+        ++own;
+        if (j > i) cnt[(size_t)j + 1].fetch_add(1, std::memory_order_relaxed);
+      }
+      below[(size_t)i] = own;                                   // (own entries for now)
     }
+  });
+  RLH_REQUIRE(bad_kind.load() != 1, "rlh_csr_create_upper: column index out of range in row %lld", (long long)bad_row.load());
+  RLH_REQUIRE(bad_kind.load() != 2, "rlh_csr_create_upper: the column indices of row %lld are not sorted (or repeat)",
+              (long long)bad_row.load());
+  std::vector<int64_t> rp((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t mirrored = cnt[(size_t)i + 1].load(std::memory_order_relaxed);
+    rp[(size_t)i + 1] = rp[(size_t)i] + mirrored + below[(size_t)i];
+    below[(size_t)i] = mirrored;
+    cnt[(size_t)i].store(rp[(size_t)i], std::memory_order_relaxed);     // where the next mirrored entry of row i goes
   }
-  for (int64_t i = 0; i < n; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
   std::vector<int32_t> idx((size_t)rp[(size_t)n]);
   std::vector<T> val((size_t)rp[(size_t)n]);
-  std::vector<int64_t> next_below(rp.begin(), rp.end() - 1);      // where the next mirrored entry of a row goes
-  for (int64_t i = 0; i < n; ++i) {
-    int64_t w = rp[(size_t)i] + below[(size_t)i];                 // the row's own entries follow its mirrored ones
-    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
-      const int32_t j = indices[e];
-      if (j < i) continue;
-      idx[(size_t)w] = j; val[(size_t)w] = values[e]; ++w;
-      if (j > i) {
-        const int64_t d = next_below[(size_t)j]++;
-        idx[(size_t)d] = (int32_t)i; val[(size_t)d] = conj_of(values[e]);
+  host_parallel(64, [&](int t, int nt) {
+    for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+      int64_t w = rp[(size_t)i] + below[(size_t)i];               // the row's own entries follow its mirrored ones
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (j < i) continue;
+        idx[(size_t)w] = j; val[(size_t)w] = values[e]; ++w;
+        if (j > i) {
+          const int64_t d = cnt[(size_t)j].fetch_add(1, std::memory_order_relaxed);
+          idx[(size_t)d] = (int32_t)i; val[(size_t)d] = conj_of(values[e]);
+        }
       }
     }
-  }
+  });
+  // the mirrored entries of a row arrive in whatever order the threads reached them: ascending column order restored
+  host_parallel(64, [&](int t, int nt) {
+    std::vector<std::pair<int32_t, T>> tmp;
+    for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) {
+      const int64_t b0 = rp[(size_t)i], m = below[(size_t)i];
+      bool sorted = true;
+      for (int64_t k = 1; k < m && sorted; ++k) sorted = idx[(size_t)(b0 + k - 1)] < idx[(size_t)(b0 + k)];
+      if (sorted) continue;
+      tmp.resize((size_t)m);
+      for (int64_t k = 0; k < m; ++k) tmp[(size_t)k] = {idx[(size_t)(b0 + k)], val[(size_t)(b0 + k)]};
+      std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, T> &x, const std::pair<int32_t, T> &y) { return x.first < y.first; });
+      for (int64_t k = 0; k < m; ++k) { idx[(size_t)(b0 + k)] = tmp[(size_t)k].first; val[(size_t)(b0 + k)] = tmp[(size_t)k].second; }
+    }
+  });
+  clk.lap("mirror the upper triangle");
   return rlh_csr_create(out, dtype, n, n, rp.data(), idx.data(), val.data());
 }
 
@@ -1986,6 +2038,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   RLH_REQUIRE(dtype_valid(dtype), "rlh_csr_create: unknown dtype %d", dtype);
   RLH_REQUIRE(n_rows >= 0 && n_cols >= 0 && n_cols < ((int64_t)1 << 31), "rlh_csr_create: bad shape");
   RLH_REQUIRE(indptr != nullptr, "rlh_csr_create: null indptr");
+  PhaseClock clk;
   const int64_t nnz = indptr[n_rows] - indptr[0];
   RLH_REQUIRE(indptr[0] == 0 && nnz >= 0, "rlh_csr_create: indptr must be 0-based and non-decreasing");
   RLH_REQUIRE(nnz == 0 || (indices && values), "rlh_csr_create: null indices/values");
@@ -1994,6 +2047,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   for (int64_t e = 0; e < nnz; ++e)
     RLH_REQUIRE(indices[e] >= 0 && indices[e] < n_cols, "rlh_csr_create: column index %d out of range at entry %lld",
                 indices[e], (long long)e);
+  clk.lap("argument checks");
   rlh_csr *h = new rlh_csr();
   h->dtype = dtype; h->n_rows = n_rows; h->n_cols = n_cols; h->nnz = nnz;
   h->slice_ptr = nullptr; h->cols = nullptr; h->vals = nullptr;

@@ -15,8 +15,10 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <complex>
-#include <queue>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -69,93 +71,200 @@ namespace rlh {
 static inline double mag(double v) { return fabs(v); }
 static inline double mag(const std::complex<double> &v) { return std::abs(v); }
 
+// Row i of the factorisation reads the finished U rows k < i it eliminates with, in increasing k: the rows are claimed
+// in order by a pool of host threads, and a thread that needs a row still being worked on waits for that row alone (a
+// per-row flag; the lowest unfinished row never waits, so there is no deadlock).  Every row performs exactly the
+// operations of the sequential algorithm in the same order, so the factors are bit-identical to it whatever the number
+// of threads (tests/test_ilu_cpu.py compares with the pure-Python restatement).  A row's recent neighbours come LAST in
+// its elimination order, so what stays serial per row is one elimination step and the selection of the kept entries:
+// on an FE matrix whose rows eliminate several hundred pivots the pool scales with the thread count.
+struct IlutArena {                               // per-thread storage of finished rows (never moved: other threads read it)
+  std::vector<std::unique_ptr<char[]>> chunks;
+  size_t used = 0, cap = 0;
+  char *take(size_t bytes) {
+    bytes = (bytes + 15) & ~(size_t)15;
+    if (chunks.empty() || used + bytes > cap) {
+      cap = std::max<size_t>(bytes, (size_t)8 << 20);
+      chunks.emplace_back(new char[cap]);
+      used = 0;
+    }
+    char *p = chunks.back().get() + used;
+    used += bytes;
+    return p;
+  }
+};
+template <typename S> struct IlutRow { const int32_t *idx; const S *val; int32_t cnt; };   // U: diagonal first, then ascending
+
 template <typename S>
 static int ilut_factor(int64_t n, const int64_t *indptr, const int32_t *indices, const S *values, double tol,
                        int64_t maxfil, rlh_factors *f) {
   f->n = n;
   f->lptr.assign((size_t)n + 1, 0);
   f->uptr.assign((size_t)n + 1, 0);
-  std::vector<S> lval, uval;
-  std::vector<int32_t> &lidx = f->lidx, &uidx = f->uidx;
-  std::vector<S> w((size_t)n);
-  std::vector<int64_t> mark((size_t)n, -1);
-  std::vector<int64_t> udiag_pos((size_t)n, 0);        // position of u_kk in uval
-  std::vector<int32_t> lcand, ucand;
-  std::vector<std::pair<double, int32_t>> keep;
-  for (int64_t i = 0; i < n; ++i) {
-    double nrm = 0.0;
-    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) nrm += mag(values[e]) * mag(values[e]);
-    nrm = sqrt(nrm);
-    RLH_REQUIRE(nrm > 0.0, "rlh_ilut_factor: row %lld is empty", (long long)i);
-    const double tau = tol * nrm;
-    std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> heap;   // columns < i still to eliminate
-    ucand.clear();
-    lcand.clear();
-    mark[i] = i;
-    w[i] = S(0);
-    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
-      const int32_t j = indices[e];
-      if (mark[j] != i || j == i) {
-        if (mark[j] != i) { mark[j] = i; w[j] = S(0); }
-        if (j < i) heap.push(j); else if (j > i) ucand.push_back(j);
+  if (n == 0) return 0;
+  std::vector<IlutRow<S>> lrow((size_t)n), urow((size_t)n);
+  std::unique_ptr<std::atomic<unsigned char>[]> done(new std::atomic<unsigned char>[(size_t)n]);
+  for (int64_t i = 0; i < n; ++i) done[(size_t)i].store(0, std::memory_order_relaxed);
+  std::atomic<int64_t> next{0}, bad_row{-1};
+  std::atomic<int> failed{0};
+  // Threads pay where a row eliminates many pivots (FE matrices: hundreds per row).  The rows of a stencil do a few dozen
+  // operations each and read three or four rows another thread has just written: the cache misses cost more than the
+  // arithmetic, and the pool is slower than one thread (lap3d 100^3: 0.9 s against 0.35 s) -- such matrices stay serial.
+  // (Chunks of consecutive rows per claim were tried for them: no faster than serial, and on the FE matrix the thread of
+  // the next chunk waits for the whole chunk before it: 6.5 s against 2.4 s row by row.)
+  const int64_t chunk = 1;
+  const bool wide = indptr[n] >= 16 * n;
+  const int nthreads = wide ? (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / 256)) : 1;
+  std::vector<IlutArena> arenas((size_t)nthreads);
+
+  const bool stats = env_int("RLH_ILUT_STATS", 0) != 0;
+  std::atomic<long long> st_l{0}, st_u{0};
+  auto worker = [&](int tid) {
+    IlutArena &arena = arenas[(size_t)tid];
+    struct Slot { S w; int32_t mark; };                 // value and row stamp of a column side by side: one cache line per touch
+    std::vector<Slot> slot((size_t)n, Slot{S(0), -1});
+    std::vector<int32_t> lcand, ucand, heap;
+    std::vector<std::pair<double, int32_t>> keep;
+    const auto later = std::greater<int32_t>();
+    int64_t i = 0, chunk_end = 0;
+    for (;; ++i) {
+      if (i >= chunk_end) {                             // the next chunk of consecutive rows
+        i = next.fetch_add(chunk, std::memory_order_relaxed);
+        chunk_end = std::min(n, i + chunk);
       }
-      w[j] += values[e];
-    }
-    // (duplicate column indices in a row were summed above; a duplicate may have been pushed twice)
-    int32_t last = -1;
-    while (!heap.empty()) {
-      const int32_t k = heap.top();
-      heap.pop();
-      if (k == last) continue;
-      last = k;
-      const S lik = w[k] / uval[(size_t)udiag_pos[k]];
-      if (mag(lik) < tau) continue;                       // first dropping rule
-      w[k] = lik;
-      lcand.push_back(k);
-      for (int64_t e = udiag_pos[k] + 1; e < f->uptr[k + 1]; ++e) {      // row k of U beyond its diagonal
-        const int32_t j = uidx[(size_t)e];
-        if (mark[j] != i) {
-          mark[j] = i;
-          w[j] = S(0);
-          if (j < i) heap.push(j); else ucand.push_back(j);
+      if (i >= n || failed.load(std::memory_order_relaxed)) break;
+      double nrm = 0.0;
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) nrm += mag(values[e]) * mag(values[e]);
+      nrm = sqrt(nrm);
+      if (!(nrm > 0.0)) {
+        bad_row.store(i);
+        failed.store(1);
+        break;
+      }
+      const double tau = tol * nrm;
+      heap.clear();                                     // columns < i still to eliminate (min-heap)
+      ucand.clear();
+      lcand.clear();
+      slot[i].mark = (int32_t)i;
+      slot[i].w = S(0);
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (slot[j].mark != i || j == i) {
+          if (slot[j].mark != i) { slot[j].mark = (int32_t)i; slot[j].w = S(0); }
+          if (j < i) { heap.push_back(j); std::push_heap(heap.begin(), heap.end(), later); }
+          else if (j > i) ucand.push_back(j);
         }
-        w[j] -= lik * uval[(size_t)e];
+        slot[j].w += values[e];
       }
+      // (duplicate column indices in a row were summed above; a duplicate may have been pushed twice)
+      int32_t last = -1;
+      bool bail = false;
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), later);
+        const int32_t k = heap.back();
+        heap.pop_back();
+        if (k == last) continue;
+        last = k;
+        if (!heap.empty()) {                              // the next pivot's row was written by another thread: start fetching it
+          const int32_t kn = heap.front();
+          if (done[(size_t)kn].load(std::memory_order_acquire)) {
+            const IlutRow<S> &un = urow[(size_t)kn];
+            __builtin_prefetch(un.idx);
+            __builtin_prefetch(un.val);
+            __builtin_prefetch((const char *)un.val + 64);
+            __builtin_prefetch((const char *)un.val + 128);
+            __builtin_prefetch((const char *)un.idx + 64);
+          }
+        }
+        if (!done[(size_t)k].load(std::memory_order_acquire)) {          // row k is still being factorised by another thread
+          unsigned spins = 0;
+          while (!done[(size_t)k].load(std::memory_order_acquire)) {
+            if (failed.load(std::memory_order_relaxed)) { bail = true; break; }
+            if (++spins > 64) std::this_thread::yield();
+          }
+          if (bail) break;
+        }
+        const IlutRow<S> &uk = urow[(size_t)k];
+        const S lik = slot[k].w / uk.val[0];
+        if (mag(lik) < tau) continue;                       // first dropping rule
+        slot[k].w = lik;
+        lcand.push_back(k);
+        for (int32_t e = 1; e < uk.cnt; ++e) {              // row k of U beyond its diagonal
+          const int32_t j = uk.idx[e];
+          if (slot[j].mark != i) {
+            slot[j].mark = (int32_t)i;
+            slot[j].w = S(0);
+            if (j < i) { heap.push_back(j); std::push_heap(heap.begin(), heap.end(), later); }
+            else ucand.push_back(j);
+          }
+          slot[j].w -= lik * uk.val[e];
+        }
+      }
+      if (bail) break;
+      // second dropping rule: the p largest of each part (all of them already >= tau in L)
+      auto select = [&](std::vector<int32_t> &cand, bool threshold) {
+        keep.clear();
+        for (int32_t j : cand) {
+          const double a = mag(slot[j].w);
+          if (!threshold || a >= tau) keep.push_back({a, j});
+        }
+        if ((int64_t)keep.size() > maxfil) {
+          std::nth_element(keep.begin(), keep.begin() + maxfil, keep.end(),
+                           [](const std::pair<double, int32_t> &x, const std::pair<double, int32_t> &y) {
+                             return x.first > y.first || (x.first == y.first && x.second < y.second);
+                           });
+          keep.resize((size_t)maxfil);
+        }
+        cand.clear();
+        for (auto &kv : keep) cand.push_back(kv.second);
+        std::sort(cand.begin(), cand.end());
+      };
+      if (stats) { st_l += (long long)lcand.size(); st_u += (long long)ucand.size(); }
+      // (a column enters ucand once: its stamp is set when it does -- no sort / unique pass over the few hundred
+      // candidates here, on the part of a row's work that no other thread can overlap)
+      select(lcand, false);
+      select(ucand, true);
+      {
+        const size_t nl = lcand.size(), nu = ucand.size() + 1;
+        int32_t *li = (int32_t *)arena.take(nl * sizeof(int32_t));
+        S *lv = (S *)arena.take(nl * sizeof(S));
+        for (size_t q = 0; q < nl; ++q) { li[q] = lcand[q]; lv[q] = slot[lcand[q]].w; }
+        lrow[(size_t)i] = IlutRow<S>{li, lv, (int32_t)nl};
+        int32_t *ui = (int32_t *)arena.take(nu * sizeof(int32_t));
+        S *uv = (S *)arena.take(nu * sizeof(S));
+        S d = slot[i].w;
+        if (mag(d) < tau || mag(d) == 0.0) d = S(tau > 0.0 ? tau : 1e-4 * nrm);   // small pivot: replaced, as dcsrilut does
+        ui[0] = (int32_t)i;
+        uv[0] = d;
+        for (size_t q = 1; q < nu; ++q) { ui[q] = ucand[q - 1]; uv[q] = slot[ucand[q - 1]].w; }
+        urow[(size_t)i] = IlutRow<S>{ui, uv, (int32_t)nu};
+      }
+      done[(size_t)i].store(1, std::memory_order_release);
     }
-    // second dropping rule: the p largest of each part (all of them already >= tau in L)
-    auto select = [&](std::vector<int32_t> &cand, bool threshold) {
-      keep.clear();
-      for (int32_t j : cand) {
-        const double a = mag(w[j]);
-        if (!threshold || a >= tau) keep.push_back({a, j});
-      }
-      if ((int64_t)keep.size() > maxfil) {
-        std::nth_element(keep.begin(), keep.begin() + maxfil, keep.end(),
-                         [](const std::pair<double, int32_t> &x, const std::pair<double, int32_t> &y) {
-                           return x.first > y.first || (x.first == y.first && x.second < y.second);
-                         });
-        keep.resize((size_t)maxfil);
-      }
-      cand.clear();
-      for (auto &kv : keep) cand.push_back(kv.second);
-      std::sort(cand.begin(), cand.end());
-    };
-    select(lcand, false);
-    std::sort(ucand.begin(), ucand.end());
-    ucand.erase(std::unique(ucand.begin(), ucand.end()), ucand.end());
-    select(ucand, true);
-    for (int32_t j : lcand) { lidx.push_back(j); lval.push_back(w[j]); }
-    f->lptr[i + 1] = (int64_t)lidx.size();
-    S d = w[i];
-    if (mag(d) < tau || mag(d) == 0.0) d = S(tau > 0.0 ? tau : 1e-4 * nrm);   // small pivot: replaced, as dcsrilut does
-    udiag_pos[i] = (int64_t)uidx.size();
-    uidx.push_back((int32_t)i);
-    uval.push_back(d);
-    for (int32_t j : ucand) { uidx.push_back(j); uval.push_back(w[j]); }
-    f->uptr[i + 1] = (int64_t)uidx.size();
+  };
+  host_parallel(nthreads, [&](int t, int) { worker(t); });
+  RLH_REQUIRE(!failed.load(), "rlh_ilut_factor: row %lld is empty", (long long)bad_row.load());
+  if (stats) fprintf(stderr, "ilut: %lld rows, pivots per row %.1f, U candidates per row %.1f\n", (long long)n, (double)st_l.load() / n, (double)st_u.load() / n);
+  // rows -> CSR
+  for (int64_t i = 0; i < n; ++i) {
+    f->lptr[(size_t)i + 1] = f->lptr[(size_t)i] + lrow[(size_t)i].cnt;
+    f->uptr[(size_t)i + 1] = f->uptr[(size_t)i] + urow[(size_t)i].cnt;
   }
-  f->lval.assign((const char *)lval.data(), (const char *)(lval.data() + lval.size()));
-  f->uval.assign((const char *)uval.data(), (const char *)(uval.data() + uval.size()));
+  f->lidx.resize((size_t)f->lptr[(size_t)n]);
+  f->uidx.resize((size_t)f->uptr[(size_t)n]);
+  f->lval.resize((size_t)f->lptr[(size_t)n] * sizeof(S));
+  f->uval.resize((size_t)f->uptr[(size_t)n] * sizeof(S));
+  S *lval = (S *)f->lval.data(), *uval = (S *)f->uval.data();
+  auto gather = [&](int64_t r0, int64_t r1) {
+    for (int64_t i = r0; i < r1; ++i) {
+      const IlutRow<S> &l = lrow[(size_t)i], &u = urow[(size_t)i];
+      std::copy(l.idx, l.idx + l.cnt, f->lidx.begin() + f->lptr[(size_t)i]);
+      std::copy(l.val, l.val + l.cnt, lval + f->lptr[(size_t)i]);
+      std::copy(u.idx, u.idx + u.cnt, f->uidx.begin() + f->uptr[(size_t)i]);
+      std::copy(u.val, u.val + u.cnt, uval + f->uptr[(size_t)i]);
+    }
+  };
+  host_parallel(nthreads, [&](int t, int nt) { gather(n * t / nt, n * (t + 1) / nt); });
   return 0;
 }
 
