@@ -314,6 +314,45 @@ def solve_ilu_pair(side):
     return out
 
 
+def solve_ilu_large(side):
+    """The reference's configuration -- partial_hevp(A, T=IncompleteLU(A), which=10), ILUT(1e-6, fill 1) -- at a size where
+    only the GPU leg is run (the CPU port needs minutes there): set-up (host ILUT + device triangular-solve set-up), one
+    application of the preconditioner, seconds to ten eigenpairs, eigenvalue error against the analytic spectrum."""
+    from raleigh_amd import _lib
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.algebra.hip import Vectors
+    from raleigh_amd.algebra.hip.precond import IncompleteLU
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.synthetic import lap3d_rows
+    from oracle.sparse import lap3d_eigenvalues
+    n = side ** 3
+    A = lap3d_rows(side, side, side, 1.0, 1.01, 1.02, 0, n)
+    ana = lap3d_eigenvalues(side, side, side, 1.0, 1.01, 1.02, 10)
+    t0 = time.perf_counter()
+    T = IncompleteLU(A)
+    T.factorize()
+    _lib_sync()
+    t_setup = time.perf_counter() - t0
+    m = 16
+    B_, Z_ = Vectors(n, m), Vectors(n, m)
+    B_.fill_random()
+    ta = timed_calls(_lib.lib(), lambda: T.apply(B_, Z_), 5)
+    del B_, Z_
+    np.random.seed(1)
+    opt = Options()
+    opt.max_iter = 3000
+    t0 = time.perf_counter()
+    lmd, x, status = partial_hevp(A, T=T, which=10, tol=1e-6, verb=-1, opt=opt)
+    seconds = time.perf_counter() - t0
+    return {'problem': 'lap3d %d^3 (n=%d), 10 smallest eigenpairs, eigenvector tol 1e-6, ILUT(1e-6, fill 1) as the reference\'s '
+                       'IncompleteLU, GPU only' % (side, n),
+            'seconds': round(seconds, 3), 'setup_seconds': round(t_setup, 3),
+            'setup_what': 'host ILUT + device triangular-solve set-up (the operator itself is built inside the timed solve)',
+            'status': int(status), 'iterations': int(partial_hevp.last['iterations']), 'levels': list(T.levels),
+            'ilu_apply_ms_16_vectors': round(ta, 3), 'ilu_apply_gbs': round(T.chain().algorithmic_bytes(m) / ta / 1e6, 1),
+            'max_rel_eigenvalue_error': float(np.max(np.abs(lmd[:10] - ana) / ana)) if status == 0 and len(lmd) >= 10 else None}
+
+
 def timed_calls(L, fn, reps):
     """Median HIP-event time (ms) of `reps` back-to-back calls of fn on the library stream."""
     from raleigh_amd import _lib
@@ -620,6 +659,8 @@ def main():
                          'halo exchange included (a rank then exchanges with itself)')
     ap.add_argument('--solve-side', type=int, default=215,
                     help='lap3d side of the end-to-end "seconds to 10 eigenpairs" run (0: skip)')
+    ap.add_argument('--ilu-large-side', type=int, default=160,
+                    help='lap3d side of the GPU-only solve with the reference\'s ILU preconditioner (0: skip)')
     ap.add_argument('--ilu-side', type=int, default=64,
                     help='lap3d side of the GPU-vs-CPU solve with the reference\'s ILU preconditioner (0: skip)')
     args = ap.parse_args()
@@ -868,6 +909,8 @@ def main():
     if world == 1 and comm is None:
         if args.ilu_side > 0:
             ok = guarded('solve_ilu', lambda: solve_ilu_pair(args.ilu_side)) and ok
+        if args.ilu_large_side > 0:
+            ok = guarded('solve_ilu_large', lambda: solve_ilu_large(args.ilu_large_side)) and ok
         if not args.no_configs:
             ok = guarded('configs', lambda: config_legs(L)) and ok
         if not args.no_cpu_baseline:
