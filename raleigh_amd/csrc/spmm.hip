@@ -1386,10 +1386,25 @@ static int stack_dispatch(rlh_csr *h, int part, int64_t m, const T *X, int64_t l
   if (sizeof(T) == 4 && !cplx && part == 0 && H == nullptr && env_int("RLH_SPMM_STACK_DMA", 1) < 2) dma = false;
   // the last staging group may reach up to 7 columns past n_cols: inside the block's leading dimension, or not this way
   if (h->stk_overhang > 0 && (H != nullptr && n_own != h->n_cols ? ldh < h->n_cols - n_own + h->stk_overhang
-                                                                  : ldx < h->n_cols + h->stk_overhang))
+                                                                  : ldx < h->n_cols + h->stk_overhang)) {
+    static bool said = false;
+    if (!said && env_int("RLH_SPMM_VERBOSE", 0) != 0) {
+      said = true;
+      fprintf(stderr, "rlh_spmm_part: stacks not used (overhang %d, ldh %lld, ldx %lld, n_cols %lld, n_own %lld)\n", h->stk_overhang,
+              (long long)ldh, (long long)ldx, (long long)h->n_cols, (long long)n_own);
+    }
     return 0;
+  }
   if (part != 0 || H != nullptr) {
-    if (!dma || (H != nullptr && n_own != h->n_cols && !(h->stk_aligned && n_own % EPL == 0))) return 0;
+    if (!dma || (H != nullptr && n_own != h->n_cols && !(h->stk_aligned && n_own % EPL == 0))) {
+      static bool said = false;
+      if (!said && env_int("RLH_SPMM_VERBOSE", 0) != 0) {
+        said = true;
+        fprintf(stderr, "rlh_spmm_part: stacks not used (dma %d, aligned %d, n_own %lld, gmax %d, overhang %d)\n", (int)dma,
+                h->stk_aligned, (long long)n_own, h->stk_gmax, h->stk_overhang);
+      }
+      return 0;
+    }
     if (part != 0)
       if (int rc = stack_split(h, n_own)) return rc;
   }
@@ -1757,12 +1772,21 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   clk.lap("stack: windows");
   // a stack whose image does not fit (grid planes half a row block out of step with the blocks: 126^2 rows = 15.5
   // blocks) is taken apart into stacks of one
+  // ... and so is a stack of a real type whose image fits the register-staged kernel's buffer but not a slot of the LDS-DMA
+  // ring, as long as such stacks are few (the blocks of a row shard next to its halo columns: their windows lie in two far
+  // apart column ranges): one oversized stack would otherwise take the LDS-DMA kernel -- the only one that serves row
+  // shards -- away from the whole operator (the forced one-rank run of lap3d 215^3 fell back to the unstacked kernel that
+  // way: 1.33 instead of 1.12 ms per product)
+  constexpr int DMAG = StkRing<T>::SLOT / (64 * (int)sizeof(T));
+  int64_t over_dma = 0;
+  for (int64_t sb = 0; sb < nst; ++sb) over_dma += ngroups[(size_t)sb] > DMAG && members[(size_t)(sb * R + 1)] >= 0;
+  const int CAPG = (over_dma > 0 && over_dma * 20 <= nst) ? std::min(BUFG, DMAG) : BUFG;
   bool split = false;
-  for (int64_t sb = 0; sb < nst && !split; ++sb) split = ngroups[(size_t)sb] > BUFG && members[(size_t)(sb * R + 1)] >= 0;
+  for (int64_t sb = 0; sb < nst && !split; ++sb) split = ngroups[(size_t)sb] > CAPG && members[(size_t)(sb * R + 1)] >= 0;
   if (split) {
     std::vector<int32_t> again;
     for (int64_t sb = 0; sb < nst; ++sb) {
-      if (ngroups[(size_t)sb] <= BUFG || members[(size_t)(sb * R + 1)] < 0) {
+      if (ngroups[(size_t)sb] <= CAPG || members[(size_t)(sb * R + 1)] < 0) {
         for (int r = 0; r < R; ++r) again.push_back(members[(size_t)(sb * R + r)]);
         continue;
       }
