@@ -70,7 +70,7 @@ struct rlh_csr {
   // windows overlap (for a 3-D stencil two blocks one grid plane apart) and stages the union of their windows once
   int64_t stk_blocks;      // stacks; 0: not built
   WellMeta *stk_meta;      // device, per stack (eoff counts slots: member r's 8 slots start at eoff + 8 r)
-  int32_t *stk_member;     // device, kStkR per stack: the 1024-row blocks of the stack (-1: none)
+  int32_t *stk_member;     // device, kStkR pairs per stack: (first row, rows) of the stack's row blocks ((0, 0): none)
   int32_t *stk_gsrc;       // device
   uint16_t *stk_idx;       // device
   void *stk_vals;          // device

@@ -555,8 +555,8 @@ __global__ __launch_bounds__(1024) void well_stack_kernel(const WellMeta *__rest
     unsigned ixb[R][PACK ? WMAX / 2 : WMAX];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int32_t mb = member[sb * R + r];
-      row[r] = mb >= 0 ? (int64_t)mb * kWellRows + tid : n_rows;     // (no such member: its slots hold zeros)
+      const int2 mr = reinterpret_cast<const int2 *>(member)[sb * R + r];       // first row, rows (0: no such member)
+      row[r] = tid < mr.y ? (int64_t)mr.x + tid : n_rows;             // (no such row: its slots hold zeros)
       unsigned px[WMAX];
       well_load_entries<T, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
 #pragma unroll
@@ -761,12 +761,12 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
     int nmem = 0;                                  // members present: the first nmem (a stack of one: the plain block)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int32_t mb = member[sb * R + r];
-      if (mb >= 0) {
+      const int2 mr = reinterpret_cast<const int2 *>(member)[sb * R + r];       // first row, rows (0: no such member)
+      if (mr.y > 0) {
         nmem = r + 1;
-        whole = whole && ((int64_t)mb + 1) * kWellRows <= n_rows;
+        whole = whole && mr.y == kWellRows;
       }
-      row[r] = mb >= 0 ? (int64_t)mb * kWellRows + tid : n_rows;
+      row[r] = tid < mr.y ? (int64_t)mr.x + tid : n_rows;
       unsigned px[WMAX];
       // (not for 16-byte elements: the second path costs complex128 six spilled registers, and scratch traffic would
       // sit in the same counter as the DMAs)
@@ -845,8 +845,9 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
       // unfinished DMA through the count; if they are still outstanding this waits for one more vector than necessary
       // (RLH_SPMM_STACK_DBG & 16 counts them as before: the same time to within the noise).
       const int later = m - 1 - j < D - 1 ? m - 1 - j : D - 1;
-      if (whole) wait_vm_outstanding(((DBG & 1) ? 0 : later * mine) + ((DBG & 16) ? (j < D ? j : D) * nmem : 0));
-      else wait_vm_le<0>();
+      // (a short member -- the last block of the matrix, or the plane-aligned blocks -- changes nothing here: the count
+      // rests on the DMAs alone, whatever stores a wave does or does not issue)
+      wait_vm_outstanding(((DBG & 1) ? 0 : later * mine) + ((DBG & 16) && whole ? (j < D ? j : D) * nmem : 0));
       __builtin_amdgcn_s_barrier();
       if (j + D < m) issue(j + D);
       compute(j);
@@ -1139,12 +1140,14 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
     int nmem = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int32_t mb = member[sb * R + r];
-      if (mb >= 0) {
+      const int2 mr = reinterpret_cast<const int2 *>(member)[sb * R + r];       // first row (a multiple of 8 here), rows
+      if (mr.y > 0) {
         nmem = r + 1;
-        whole = whole && ((int64_t)mb + 1) * kWellRows <= n_rows;
+        whole = whole && mr.y == kWellRows;
       }
-      row0[r] = mb >= 0 ? (int64_t)mb * kWellRows + (int64_t)wave * 64 : n_rows;
+      // (float32 operators keep the uniform 1024-row blocks: a short member can only be the last block of the matrix, so
+      // "row < n_rows" below is "row is in the member")
+      row0[r] = mr.y > 0 ? (int64_t)mr.x + (int64_t)wave * 64 : n_rows;
       unsigned px[WMAX];
       if (pat) well_load_entries_pat<float, WMAX>(vals, pat, dtab, idx, mt.eoff + 8 * r, sb * R + r, tid, v[r], px);
       else well_load_entries<float, WMAX>(vals, idx, mt.eoff + 8 * r, tid, WMAX, v[r], px);
@@ -1687,6 +1690,24 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   return 0;
 }
 
+// The far stride of a grid operator: the offset (largest column - row) most rows share, e.g. one grid plane for a 3-D
+// stencil (0: fewer than 60 % of the sampled rows agree).  Row blocks of a stack are partners one such stride apart.
+static int64_t far_stride(const int64_t *indptr, const int32_t *indices, int64_t n) {
+  std::unordered_map<int64_t, int64_t> count;
+  int64_t samples = 0;
+  const int64_t step = std::max<int64_t>(1, n / 50000);
+  for (int64_t i = 0; i < n; i += step) {
+    if (indptr[i + 1] == indptr[i]) continue;
+    const int64_t d = (int64_t)indices[indptr[i + 1] - 1] - i;
+    ++samples;
+    if (d > 0) ++count[d];
+  }
+  int64_t best = 0, best_count = 0;
+  for (const auto &kv : count)
+    if (kv.second > best_count || (kv.second == best_count && kv.first < best)) { best = kv.first; best_count = kv.second; }
+  return best_count * 10 >= samples * 6 ? best : 0;
+}
+
 // Host side of the stacked layout ("Stacked blocks" above): the stacks by greedy matching on the window-overlap graph of
 // the 1024-row blocks, then windows / staging groups / entries per stack exactly as well_build lays them out per block.
 // Built only where it stages at least 10 % less than the unstacked layout (RLH_SPMM_STACK=2 builds it regardless, 0 never).
@@ -1707,6 +1728,10 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   // 222 blocks: 12.4 us as blocks, 14.1 us as stacks)
   if (mode == 0 || nblocks < 2 || (mode < 2 && nblocks < 4 * (int64_t)ctx().num_cu)) return 0;
   PhaseClock clk;
+  // ---- the row ranges of the blocks: uniform 1024-row blocks, paired by greedy matching on the window-overlap graph
+  std::vector<int64_t> brow;
+  std::vector<int32_t> owner, members;
+  for (int64_t b = 0; b <= nblocks; ++b) brow.push_back(std::min(b * kWellRows, n));
   // overlap of block b's windows with the rows of block c, both directions summed
   std::vector<std::vector<std::pair<int32_t, int64_t>>> adj((size_t)nblocks);
   auto bump = [&](int64_t b, int64_t c, int64_t ov) {
@@ -1725,7 +1750,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
         bump(c, b, ov);
       }
     }
-  std::vector<int32_t> owner((size_t)nblocks, -1), members;
+  owner.assign((size_t)nblocks, -1);
   int64_t next_free = 0;
   for (int64_t b = 0; b < nblocks; ++b) {
     if (owner[(size_t)b] >= 0) continue;
@@ -1749,6 +1774,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       members.push_back(best);
     }
   }
+
   int64_t nst = (int64_t)members.size() / R;
   const int64_t nc8 = (h->n_cols + 7) & ~(int64_t)7;                    // windows may end here: aligned starts at the far end too
   std::vector<std::vector<Win>> swins((size_t)nst);
@@ -1761,7 +1787,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       for (int r = 0; r < R; ++r) {
         const int64_t mb = members[(size_t)(sb * R + r)];
         if (mb < 0) continue;
-        const int64_t r0 = mb * kWellRows, r1 = std::min<int64_t>(r0 + kWellRows, n);
+        const int64_t r0 = brow[(size_t)mb], r1 = brow[(size_t)mb + 1];
         cols.insert(cols.end(), indices + indptr[r0], indices + indptr[r1]);
       }
       ngroups[(size_t)sb] = find_windows_of(cols, nc8, 32, 64, 8, swins[(size_t)sb]) / 64;
@@ -1769,6 +1795,50 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   };
   clk.lap("stack: matching");
   analyse(nst);
+  // Uniform blocks pair up exactly when the far stride of the operator (a grid plane) is a whole number of them, and well
+  // enough when it nearly is (215^2 = 45.14 blocks: 2.49 staged elements per row).  When a block and its partner one plane
+  // on are half a block out of step (126^2 = 15.5 blocks), the union of their windows outgrows a slot of the ring and the
+  // stacks fall apart into stacks of one (config 5 at 126^3: 1.03 ms against 0.82 ms at 128^3).  Then -- and only then: at
+  // 215^3 the uniform blocks are 4 % faster -- the blocks are cut plane by plane instead, ceil(plane / 1024) blocks of
+  // (nearly) equal size per plane, so that block j of a plane and block j of the next are exact translates of each other:
+  // 126^3 complex128 in 0.865 ms.  Float32 operators keep the uniform blocks (their bfloat16 step moves rows in 16-byte
+  // pieces of eight).  RLH_SPMM_STACK_ALIGN=0: never, =2: whenever a far stride exists.
+  {
+    constexpr int DMAG0 = StkRing<T>::SLOT / (64 * (int)sizeof(T));
+    const int align_mode = env_int("RLH_SPMM_STACK_ALIGN", 1);
+    int64_t apart = 0, pairs = 0;
+    for (int64_t sb = 0; sb < nst; ++sb)
+      if (members[(size_t)(sb * R + 1)] >= 0) { ++pairs; apart += ngroups[(size_t)sb] > std::min(BUFG, DMAG0); }
+    const int64_t plane = (R == 2 && DT != RLH_S && align_mode != 0 && (apart * 4 > pairs || align_mode == 2))
+                              ? far_stride(indptr, indices, n) : 0;
+    if (plane > kWellRows && plane < n && plane % kWellRows != 0) {
+      brow.clear();
+      members.clear();
+      std::vector<int64_t> first_of_plane;              // block id of the first block of every plane
+      brow.push_back(0);
+      for (int64_t p0 = 0; p0 < n; p0 += plane) {
+        const int64_t len = std::min(plane, n - p0), k = (len + kWellRows - 1) / kWellRows;
+        first_of_plane.push_back((int64_t)brow.size() - 1);
+        for (int64_t j = 1; j <= k; ++j) brow.push_back(p0 + len * j / k);
+      }
+      first_of_plane.push_back((int64_t)brow.size() - 1);
+      const int64_t planes = (int64_t)first_of_plane.size() - 1;
+      for (int64_t p = 0; p < planes; p += 2) {
+        const int64_t b0 = first_of_plane[(size_t)p], k0 = first_of_plane[(size_t)p + 1] - b0;
+        const int64_t b1 = p + 1 < planes ? first_of_plane[(size_t)p + 1] : -1, k1 = p + 1 < planes ? first_of_plane[(size_t)p + 2] - b1 : 0;
+        for (int64_t j = 0; j < std::max(k0, k1); ++j) {
+          if (j < k0) { members.push_back((int32_t)(b0 + j)); members.push_back(j < k1 ? (int32_t)(b1 + j) : -1); }
+          else { members.push_back((int32_t)(b1 + j)); members.push_back(-1); }
+        }
+      }
+      nst = (int64_t)members.size() / R;
+      owner.assign(brow.size() - 1, -1);
+      for (size_t k = 0; k < members.size(); ++k)
+        if (members[k] >= 0) owner[(size_t)members[k]] = (int32_t)(k / R);
+      analyse(nst);
+    }
+  }
+  const int64_t nblk = (int64_t)brow.size() - 1;
   clk.lap("stack: windows");
   // a stack whose image does not fit (grid planes half a row block out of step with the blocks: 126^2 rows = 15.5
   // blocks) is taken apart into stacks of one
@@ -1832,7 +1902,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
       const int64_t mb = members[(size_t)(sb * R + r)];
       const int64_t eoff = meta[(size_t)sb].eoff + 8 * r;
       for (int l = 0; l < kWellRows; ++l) {
-        const int64_t row = mb >= 0 ? mb * kWellRows + l : n;
+        const int64_t row = mb >= 0 && brow[(size_t)mb] + l < brow[(size_t)mb + 1] ? brow[(size_t)mb] + l : n;
         const int64_t p = row < n ? indptr[row] : 0, len = row < n ? indptr[row + 1] - p : 0;
         const uint16_t padpos = len > 0 ? (uint16_t)staged_position(ws, indices[p]) : 0;
         for (int32_t t = 0; t < 8; ++t) {
@@ -1861,7 +1931,15 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   for (int64_t sb = 0; sb < nst; ++sb) h->stk_maxcol[(size_t)sb] = swins[(size_t)sb].back().start + swins[(size_t)sb].back().len - 1;
   std::vector<int32_t> &order = h->stk_order;
   std::vector<int32_t> sched;
-  well_schedule(swins, nst, n, kWellRows, ctx().num_cu, order, &owner);
+  std::vector<int32_t> granule_owner((size_t)((n + kWellRows - 1) / kWellRows), -1);      // the stack that owns row 1024 c
+  {
+    int64_t blk = 0;
+    for (size_t c = 0; c < granule_owner.size(); ++c) {
+      while (blk + 1 < nblk && brow[(size_t)blk + 1] <= (int64_t)c * kWellRows) ++blk;
+      granule_owner[c] = owner[(size_t)blk];
+    }
+  }
+  well_schedule(swins, nst, n, kWellRows, ctx().num_cu, order, &granule_owner);
   well_layout(order, ctx().num_cu, sched, h->stk_grid);
   clk.lap("stack: schedule");
   h->stk_sched_len = (int64_t)sched.size();
@@ -1869,8 +1947,16 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   RLH_HIP(hipMemcpy(h->stk_sched, sched.data(), sched.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   RLH_HIP(hipMalloc((void **)&h->stk_meta, (size_t)nst * sizeof(WellMeta)));
   RLH_HIP(hipMemcpy(h->stk_meta, meta.data(), (size_t)nst * sizeof(WellMeta), hipMemcpyHostToDevice));
-  RLH_HIP(hipMalloc((void **)&h->stk_member, members.size() * sizeof(int32_t)));
-  RLH_HIP(hipMemcpy(h->stk_member, members.data(), members.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  {
+    std::vector<int32_t> ranges(members.size() * 2, 0);                   // (first row, rows) of every member; (0, 0): none
+    for (size_t k = 0; k < members.size(); ++k)
+      if (members[k] >= 0) {
+        ranges[2 * k] = (int32_t)brow[(size_t)members[k]];
+        ranges[2 * k + 1] = (int32_t)(brow[(size_t)members[k] + 1] - brow[(size_t)members[k]]);
+      }
+    RLH_HIP(hipMalloc((void **)&h->stk_member, ranges.size() * sizeof(int32_t)));
+    RLH_HIP(hipMemcpy(h->stk_member, ranges.data(), ranges.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   RLH_HIP(hipMalloc((void **)&h->stk_gsrc, (size_t)std::max<int64_t>(goff, 1) * sizeof(int32_t)));
   RLH_HIP(hipMemcpy(h->stk_gsrc, gsrc.data(), (size_t)goff * sizeof(int32_t), hipMemcpyHostToDevice));
   // value dictionary: the distinct 8-slot value tuples of the rows (byte-wise), given up beyond kStkMaxPatterns
@@ -1922,7 +2008,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
           int used = 0;
           const int64_t mb = members[(size_t)pb];
           for (int l = 0; l < kWellRows && dok; ++l) {
-            if (mb < 0 || mb * kWellRows + l >= n) continue;      // no such row: nothing is stored for it, any pattern will do
+            if (mb < 0 || brow[(size_t)mb] + l >= brow[(size_t)mb + 1]) continue;   // no such row: nothing is stored for it, any pattern will do
             uint16_t tup[8];
             for (int t = 0; t < 8; ++t) tup[t] = (uint16_t)(idx[(size_t)well_idx_index(eoff, t, l)] - (uint16_t)l);
             int id = -1;
@@ -1959,7 +2045,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   RLH_HIP(hipMalloc((void **)&h->stk_vals, ne * sizeof(T)));
   RLH_HIP(hipMemcpy(h->stk_idx, idx.data(), ne * sizeof(uint16_t), hipMemcpyHostToDevice));
   RLH_HIP(hipMemcpy(h->stk_vals, vals.data(), ne * sizeof(T), hipMemcpyHostToDevice));
-  h->device_bytes += nst * (int64_t)sizeof(WellMeta) + (int64_t)sched.size() * 4 + goff * 4 + (int64_t)members.size() * 4 +
+  h->device_bytes += nst * (int64_t)sizeof(WellMeta) + (int64_t)sched.size() * 4 + goff * 4 + (int64_t)members.size() * 8 +
                      (int64_t)ne * (2 + (int64_t)sizeof(T));
   h->stk_blocks = nst;
   clk.lap("stack: upload");

@@ -184,6 +184,8 @@ def test_config5_full_size_block64_operations():
     H = hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n, skew=skew)
     op = CsrOperator(H)
     assert op.layout()[0] == 'wide'
+    # planes of 126^2 = 15.5 uniform row blocks: the stacks are cut plane by plane (16 blocks of 992 / 993 rows), 63 pairs of planes
+    assert op.stacks()[0] == 63 * 16
     cx, cy, cz = lap3d_coefficients(N, N, N, 1.0, 1.01, 1.02)
     # eigenvectors of the Kronecker sum: x-factor phase^j sin(j k pi / (N + 1)), phase = conj(b) / |b|, b = -cx + i skew
     j = np.arange(1, N + 1)

@@ -605,7 +605,10 @@ def test_spmm_stacked_blocks(monkeypatch, key, m, dma, pat):
     x = rnd((m, n), key, rng)
     op = SparseSymmetricMatrix(A)
     lay = op.layout()
-    assert lay[0] == ('wide' if key in 'cz' else 'well') and lay[3] == (57 if key in 'sd' else 56) and lay[5] < 0.8 * lay[4]
+    # (float64: uniform blocks pair up out of step on this grid -- planes of 70 x 53 = 3.6 blocks -- and most pairs' images
+    # exceed a slot of the LDS-DMA ring, so the library cuts the blocks plane by plane: 4 blocks of 927 / 928 rows, 15 pairs
+    # of planes and one plane of single blocks; float32 keeps the uniform blocks; the complex grid's planes are whole blocks)
+    assert lay[0] == ('wide' if key in 'cz' else 'well') and lay[3] == {'s': 57, 'd': 64}.get(key, 56) and lay[5] < 0.8 * lay[4]
     X, Y = Vectors(x), Vectors(n, m, data_type=DT[key])
     Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
     op.apply(X, Y)
@@ -619,6 +622,44 @@ def test_spmm_stacked_blocks(monkeypatch, key, m, dma, pat):
         assert np.array_equal(Y.data(), y)
     else:
         assert cases.rel(Y.data(), y) < tol
+
+
+@pytest.mark.parametrize('key', ['d', 'c', 'z'])
+@pytest.mark.parametrize('m', [5, 16])
+def test_spmm_stacked_blocks_cut_plane_by_plane(monkeypatch, key, m):
+    """Grid planes that are not a whole number of 1024-row blocks (50 x 50 = 2.44 blocks; BASELINE config 5: 126 x 126 = 15.5):
+    the stack layout cuts its row blocks plane by plane (3 blocks of 833 / 834 rows) so that a block and its partner one
+    plane on are exact translates -- 11 pairs of planes x 3 stacks of two + the last plane's 3 single blocks = 36 stacks --
+    where uniform blocks pair up out of step (the library does so by itself only where the uniform stacks fall apart, as at
+    126^3: RLH_SPMM_STACK_ALIGN=2 asks for it here).  Against the oracle, against the unstacked kernel of the same handle (bit for
+    bit for the real type) and against a handle with uniform blocks (RLH_SPMM_STACK_ALIGN=0)."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    monkeypatch.setenv('RLH_SPMM_STACK_ALIGN', '2')
+    A = _sym(lap3d(50, 50, 23, 1.0, 1.01, 1.02), key)
+    n = A.shape[0]
+    rng = np.random.default_rng(70 + m)
+    x = rnd((m, n), key, rng)
+    op = SparseSymmetricMatrix(A)
+    assert op.layout()[3] == 36
+    X, Y = Vectors(x), Vectors(n, m, data_type=DT[key])
+    Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+    op.apply(X, Y)
+    y = Y.data()
+    tol = 2e-6 if key == 'c' else 1e-13
+    assert cases.rel(y, ops.csr_sym_apply(sp.triu(A, format='csr'), x)) < tol
+    monkeypatch.setenv('RLH_SPMM_STACK', '0')                                   # (read per call: the other layout)
+    Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+    op.apply(X, Y)
+    assert np.array_equal(Y.data(), y) if key == 'd' else cases.rel(Y.data(), y) < tol
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    monkeypatch.setenv('RLH_SPMM_STACK_ALIGN', '0')
+    uniform = SparseSymmetricMatrix(A)
+    assert uniform.layout()[3] != 36
+    Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+    uniform.apply(X, Y)
+    assert np.array_equal(Y.data(), y) if key == 'd' else cases.rel(Y.data(), y) < tol
 
 
 @pytest.mark.parametrize('key', ['d', 's', 'z'])
