@@ -420,6 +420,183 @@ __global__ __launch_bounds__(QUAD ? 512 : 256, QUAD ? 2 : ((MODE == 1 && PI <= 2
   for (int e = tid; e < VY * VX; e += 256) out[(int64_t)e * gridDim.x] = lds[e];
 }
 
+// ---------------------------------------------------------------- complex128, up to 64 x 64 columns, two operands
+// G = Y^H X for complex128 blocks of 33 .. 64 vectors (BASELINE config 5: m = 64).  The kernel above reaches 52 TF = 66 %
+// of the fp64 matrix-core rate there: every thread de-interleaves its pieces into re / im planes with sixteen scalar
+// ds_write_b64 per chunk, through registers, between two workgroup barriers.  Here nothing is de-interleaved: a complex
+// column of n elements IS a real vector of 2 n reals (re_0, im_0, re_1, ...), and with J the map (re, im) -> (im, -re)
+//     Re G = Y_r^T X_r,     Im G = Y_r^T (J X_r)
+// -- a REAL Gram of the 64 columns of Y_r against the 128 columns [X_r | J X_r] over 2 n rows: the same flops (8 n m^2),
+// a 64 x 128 panel (32 accumulator registers per wave instead of 64), and J X_r never exists: its MFMA fragment is the
+// fragment of X_r read at row ^ 1 with the sign of the odd rows flipped.  So the LDS tile is the memory layout itself,
+// and the staging is global_load_lds_dwordx4: 16 bytes per lane straight into the LDS, no staging registers, no ds_write,
+// ONE barrier per chunk, the next chunk's DMAs in flight during the whole multiply phase (two 65 KB buffers).
+//   * Chunk: 32 complex rows of all 128 columns.  One DMA instruction moves 64 pieces = rows 0 .. 31 of TWO columns, which
+//     land 512 bytes apart: columns c and c + 16 -- never part of the same 16-column fragment read -- share a slot, slots
+//     are 1040 bytes apart (== 4 dwords mod 64 banks), so the 16 lanes x 4 rows of a ds_read_b64 fall into 64 different
+//     banks per half-wave.
+//   * 1024 threads, one workgroup per CU: two groups of eight waves take the two halves of a chunk's rows; within a group
+//     wave u owns Y tiles {2 (u / 4), 2 (u / 4) + 1} x X tile u % 4 for both X_r and J X_r: 4 MFMAs and 4 fragment reads per
+//     k-step.  The groups' accumulators are added through the LDS at the end, one partial per workgroup, summed by
+//     gram_z_finalize in a fixed order (bitwise reproducible).
+//   * Columns past a window's end repeat its last column (entries never written out); rows past n in the last chunk are
+//     zeroed in the LDS by the lane that fetched them.
+constexpr int kZgRows = 32;                  // complex rows per chunk
+constexpr int kZgSlot = 1040;                // bytes per slot: two columns of 32 x 16 bytes + 16
+constexpr int kZgBuf = 64 * kZgSlot;         // one chunk
+struct ZGramArgs {
+  const c64 *X, *Y;
+  int64_t ldx, ldy, n, nchunks;
+  int mx, my;
+  double *partials;                          // [64 x 128 entries][gridDim.x]
+};
+
+template <int DBG>
+__global__ __launch_bounds__(1024) void gram_z_dma_kernel(ZGramArgs a) {
+  extern __shared__ __align__(16) char zlds[];
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto dma16 = [&](const void *g, unsigned dst) {  // 16 bytes per lane to the LDS at dst + 16 lane (dst wave-uniform)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  // ---- staging plan: slots 4 wave .. 4 wave + 3; lanes 0 .. 31 the slot's first column, 32 .. 63 its second
+  const c64 *gcol[4];
+  const int lrow = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = wave * 4 + i, q = s >> 4, ii = s & 15;
+    const int c = (2 * q + (lane >> 5)) * 16 + ii;              // column of the combined window [Y | X]
+    if (c < 64) gcol[i] = a.Y + (int64_t)(c < a.my ? c : a.my - 1) * a.ldy;
+    else gcol[i] = a.X + (int64_t)(c - 64 < a.mx ? c - 64 : a.mx - 1) * a.ldx;
+  }
+  auto issue = [&](int64_t chunk, unsigned buf) {
+    int64_t row = chunk * kZgRows + lrow;
+    if (row > a.n - 1) row = a.n - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr ((DBG & 1) != 0) break;
+      dma16(gcol[i] + row, buf * (unsigned)kZgBuf + (unsigned)(wave * 4 + i) * (unsigned)kZgSlot);
+    }
+  };
+  // ---- multiply plan
+  const int grp = wave >> 3, u = wave & 7, yp = u >> 2, xj = u & 3;
+  const int fr = lane & 15, fk = lane >> 4;
+  const unsigned rbase = (unsigned)grp * 256u;                    // this group's first real row, in bytes
+  const unsigned ya0 = (unsigned)(yp * 16 + fr) * (unsigned)kZgSlot + rbase, ya1 = ya0 + 512u;
+  const unsigned xo = (unsigned)((2 + (xj >> 1)) * 16 + fr) * (unsigned)kZgSlot + (unsigned)(xj & 1) * 512u + rbase;
+  const unsigned k8 = (unsigned)fk * 8u, k8j = (unsigned)(fk ^ 1) * 8u;
+  const double sgn = (fk & 1) ? -1.0 : 1.0;
+  acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0.0, 0.0, 0.0, 0.0};
+
+  int64_t c = blockIdx.x;
+  unsigned buf = 0;
+  if (c < a.nchunks) issue(c, 0);
+  for (; c < a.nchunks; c += gridDim.x, buf ^= 1u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of chunk c have landed
+    if ((c + 1) * kZgRows > a.n && c * kZgRows + lrow >= a.n) {   // (last chunk) rows past the end: zeros
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<d2 *>(zlds + buf * (unsigned)kZgBuf + (unsigned)(wave * 4 + i) * (unsigned)kZgSlot + (unsigned)lane * 16u) = d2{0.0, 0.0};
+    }
+    __syncthreads();                                              // everybody's pieces; and chunk c - 1 has been multiplied
+    const int64_t next = c + gridDim.x;
+    if (next < a.nchunks) issue(next, buf ^ 1u);
+    const char *base = zlds + buf * (unsigned)kZgBuf;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if constexpr ((DBG & 2) != 0) break;
+      const unsigned ro = (unsigned)ks * 32u;
+      const double fa0 = *reinterpret_cast<const double *>(base + ya0 + ro + k8);
+      const double fa1 = *reinterpret_cast<const double *>(base + ya1 + ro + k8);
+      const double fb = *reinterpret_cast<const double *>(base + xo + ro + k8);
+      const double fj = sgn * *reinterpret_cast<const double *>(base + xo + ro + k8j);
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fj, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fj, acc[1][1], 0, 0, 0);
+    }
+  }
+  // ---- the two groups' panels added in a fixed order, one partial per workgroup
+  __syncthreads();
+  acc_t *red = reinterpret_cast<acc_t *>(zlds);                   // [wave u][tile 0 .. 3][lane]
+  if (grp == 1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[(u * 4 + t) * 64 + lane] = acc[t >> 1][t & 1];
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const acc_t o = red[(u * 4 + t) * 64 + lane];
+      const acc_t v = acc[t >> 1][t & 1];
+      const int ti = 2 * yp + (t >> 1);                            // Y tile
+      const int jj = (t & 1) * 64 + xj * 16 + (lane & 15);          // column of [Re | Im]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = ti * 16 + (lane >> 4) + 4 * r;
+        a.partials[(int64_t)(ii * 128 + jj) * gridDim.x + blockIdx.x] = v[r] + o[r];
+      }
+    }
+  }
+}
+
+// out[i][j] = sum over the workgroups of (Re, Im) partials, fixed order: one wave per entry
+__global__ __launch_bounds__(256) void gram_z_finalize(const double *partials, int nb, int my, int mx, c64 *out) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= my * mx) return;
+  const int i = e / mx, j = e % mx;
+  const double *pr = partials + (int64_t)(i * 128 + j) * nb, *pi = partials + (int64_t)(i * 128 + 64 + j) * nb;
+  double sr = 0.0, si = 0.0;
+  for (int b = lane; b < nb; b += 64) { sr += pr[b]; si += pi[b]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
+  if (lane == 0) out[e] = c64{sr, si};
+}
+
+static int gram_z_dma_launch(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t my, const void *Y, int64_t ldy,
+                             void *d_out) {
+  Context &c = ctx();
+  ZGramArgs a;
+  a.X = (const c64 *)X; a.Y = (const c64 *)Y; a.ldx = ldx; a.ldy = ldy; a.n = n; a.mx = (int)mx; a.my = (int)my;
+  a.nchunks = (n + kZgRows - 1) / kZgRows;
+  a.partials = (double *)c.work;
+  int64_t nb = c.num_cu;
+  if (nb > a.nchunks) nb = a.nchunks;
+  RLH_REQUIRE((size_t)nb * 64 * 128 * sizeof(double) <= kWorkspaceBytes, "rlh_gram: reduction workspace");
+#define RLH_ZG(D_)                                                                                                  \
+  do {                                                                                                              \
+    static bool attr = false;                                                                                       \
+    if (!attr) {                                                                                                    \
+      RLH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gram_z_dma_kernel<D_>),                           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kZgBuf));                         \
+      attr = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL(gram_z_dma_kernel<D_>, dim3((unsigned)nb), dim3(1024), 2 * kZgBuf, c.stream, a);             \
+  } while (0)
+  switch (getenv("RLH_GRAM_ZDBG") ? atoi(getenv("RLH_GRAM_ZDBG")) : 0) {   // (timing-only builds: 1 no DMA, 2 no multiply)
+    case 1: RLH_ZG(1); break;
+    case 2: RLH_ZG(2); break;
+    case 3: RLH_ZG(3); break;
+    default: RLH_ZG(0); break;
+  }
+#undef RLH_ZG
+  RLH_HIP(hipGetLastError());
+  const int total = (int)(my * mx);
+  hipLaunchKernelGGL(gram_z_finalize, dim3((total + 3) / 4), dim3(256), 0, c.stream, (const double *)c.work, (int)nb, (int)my,
+                     (int)mx, (c64 *)d_out);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
 // Sums the per-workgroup partials of every Gram entry in a fixed order (one wavefront per
 // entry: 64 strided partial sums, then a fixed xor-shuffle tree) and writes the (my, mx)
 // result; complex outputs recombine conj(y)*x = (RR + II) + i (RI - IR).
@@ -891,6 +1068,12 @@ static int gram_impl(int64_t n, int64_t mx, const void *X, int64_t ldx, int64_t 
     if (a.same && npi == 1 && npj == 1 && PI == PJ && PI <= 2) mode = 2;   // (longer chunks instead: 0.48 -> 0.535 ms)
     else if (!a.same && pipe >= 2 && PI * PJ <= 4) mode = 1;
     else if (PI <= 2 && PJ <= 2 && rows_cap >= 2) mode = (PI * PJ == 1 && rows_cap >= 4) ? 4 : 3;
+  }
+  // complex128, 33 .. 64 vectors on both sides, two operands: the interleaved real view on LDS-DMA staging (gram_z_dma_kernel)
+  if constexpr (DT == RLH_Z) {
+    static const int zdma = getenv("RLH_GRAM_ZDMA") ? atoi(getenv("RLH_GRAM_ZDMA")) : 1;
+    if (zdma && aligned && !a.same && mx > 32 && mx <= 64 && my > 32 && my <= 64 && n >= 64 * (int64_t)kZgRows)
+      return gram_z_dma_launch(n, mx, X, ldx, my, Y, ldy, d_out);
   }
   // windows of more than 64 real columns: 128 x 128 panels with one quadrant per wave (see gram_kernel)
   if (aligned && (vx > 64 || vy > 64) && vx > 32 && vy > 32 && env_quad()) {

@@ -77,6 +77,31 @@ def test_gram_vs_oracle(key, n, mx, my):
     assert np.array_equal(g, X.dot(Y))
 
 
+@pytest.mark.parametrize('n,mx,my', [(2048, 64, 64), (7777, 64, 64), (5003, 40, 50), (100001, 33, 64), (40000, 64, 37)])
+def test_gram_complex128_interleaved_view(n, mx, my, monkeypatch):
+    """gram_z_dma_kernel: the two-operand Gram of complex128 blocks of 33 .. 64 vectors as a real Gram of Y_r against
+    [X_r | J X_r] on LDS-DMA staging -- ragged widths (clamped columns), row counts that leave a partial chunk (zeroed
+    rows), windows inside wider blocks (other leading dimensions); against the oracle, against the workgroup kernel it
+    replaces (RLH_GRAM_ZDMA is read once per process: the other kernel is reached through a self-Gram-shaped request it
+    does not take), reproducible bit for bit."""
+    from raleigh_amd.algebra.hip import Vectors
+    rng = np.random.default_rng(n + mx)
+    x, y = rnd((mx, n), 'z', rng), rnd((my, n), 'z', rng)
+    X, Y = Vectors(x), Vectors(y)
+    g = X.dot(Y)
+    ref = ops.gram(x, y)
+    assert g.shape == (my, mx)
+    assert cases.rel(g, ref) < 1e-13 * max(1.0, np.sqrt(n) / 30)
+    assert np.array_equal(g, X.dot(Y))
+    # conj symmetry with the operands swapped (another launch of the same kernel)
+    assert cases.rel(Y.dot(X), ref.conj().T) < 1e-13 * max(1.0, np.sqrt(n) / 30)
+    # windows of wider blocks
+    wide = Vectors(n, mx + 7, data_type=np.complex128)
+    wide.select(mx, 5)
+    wide.fill(x)
+    assert np.array_equal(wide.dot(Y), g)
+
+
 @pytest.mark.parametrize('key', ['d', 's'])
 @pytest.mark.parametrize('n,mx,my', [(31, 32, 32), (64, 17, 32), (30001, 24, 17), (15000, 32, 64), (12345, 20, 50),
                                      (100003, 32, 48), (4096, 32, 33), (70001, 18, 18), (20001, 64, 64), (9000, 40, 20),
