@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce(const float *__restri
 //  * column-major tiles (the transposed product of a row-major matrix) transposed 4 x 4 in registers on
 //    the way in, so they too are written with ds_write_b128, conflict-free.
 template <int BN, int BK, bool A_KC>
-__global__ __launch_bounds__(256, (BK == 16 ? (A_KC ? 4 : 3) : 2)) void dense_mfma2_f32_kernel(DenseArgs a, float *__restrict__ part, int64_t kchunk) {
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void dense_mfma2_f32_kernel(DenseArgs a, float *__restrict__ part, int64_t kchunk) {
   constexpr int MR = 128;
   constexpr int WGN = (BN >= 64) ? 2 : 1;          // waves along the vector dimension
   constexpr int WGM = 4 / WGN;                     // waves along the output-row dimension
@@ -506,7 +506,7 @@ template <> struct Acc4<double> { using V = f64x4; };
 template <> struct Acc4<float> { using V = f32x4; };
 
 template <typename T, typename R, bool CPLX, bool A_KC, bool CONJ, int TR, int TV>
-__global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
+__global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a, T *__restrict__ part, int64_t kchunk) {
   constexpr int MR = 32 * TR, BN = 32 * TV, BK = 16, SK = BK + 2;     // 2 x 2 waves of TR x TV MFMA tiles
   constexpr int NP = CPLX ? 2 : 1;                  // planes
   constexpr int EPU = 16 / (int)sizeof(T);          // elements of T per 16-byte unit
@@ -522,6 +522,10 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
   const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves: output rows x vectors
   const int64_t i0 = (int64_t)blockIdx.x * MR;
   const int v0 = blockIdx.y * BN;
+  // gridDim.z splits K (chunks of whole K steps): the M x m output alone gives too few workgroups to fill the chip evenly --
+  // 20 000 x 128 in 64 x 64 tiles is 626 workgroups for 512 resident slots, 1.2 rounds, the second one a fifth full
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk) < a.nx ? (kbeg + kchunk) : a.nx;
   Unit ra0[UA], rb0[UB], ra1[UA], rb1[UB];      // two register sets: the tile two K steps ahead is in flight
   auto zero_unit = [](Unit &u) {
 #pragma unroll
@@ -544,16 +548,16 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
         if constexpr (MASK) {
 #pragma unroll
           for (int e = 0; e < EPU; ++e)
-            if (k + e >= a.nx) ra[q].e[e] = zero_of(T{});
+            if (k + e >= kend) ra[q].e[e] = zero_of(T{});
         }
       } else {                                      // EPU consecutive output rows at one k
         const int kk = u / (MR / EPU), rq = (u % (MR / EPU)) * EPU;
         int64_t i = i0 + rq;
         i = (i + EPU <= a.lda) ? i : 0;
         const int64_t k = k0 + kk;
-        const int64_t kc = (!MASK || k < a.nx) ? k : 0;
+        const int64_t kc = (!MASK || k < kend) ? k : 0;
         ra[q] = *reinterpret_cast<const Unit *>(A + kc * a.lda + i);
-        if constexpr (MASK) { if (k >= a.nx) zero_unit(ra[q]); }
+        if constexpr (MASK) { if (k >= kend) zero_unit(ra[q]); }
       }
     }
 #pragma unroll
@@ -568,12 +572,12 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
       if constexpr (MASK) {
 #pragma unroll
         for (int e = 0; e < EPU; ++e)
-          if (k + e >= a.nx) rb[q].e[e] = zero_of(T{});
+          if (k + e >= kend) rb[q].e[e] = zero_of(T{});
       }
     }
   };
   auto load_tiles = [&](int64_t k0, Unit (&ra)[UA], Unit (&rb)[UB]) {
-    if (k0 + BK > a.nx) load_tiles_as(k0, ra, rb, std::true_type{});       // (wave-uniform: the last K step only)
+    if (k0 + BK > kend) load_tiles_as(k0, ra, rb, std::true_type{});       // (wave-uniform: the last K step only)
     else load_tiles_as(k0, ra, rb, std::false_type{});
   };
   auto put = [](R *re, R *im, int at, const T &v) {          // one element into its plane(s)
@@ -645,33 +649,33 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
   // K steps in pairs: at step t the LDS buffer t % 2 holds tile t, one register set holds tile t + 1 and the other
   // receives tile t + 2 -- a global load has a whole step, its MFMAs and a barrier to arrive before it is needed
   // (with one set the matrix cores of this kernel sat idle 57 % of the time behind s_waitcnt)
-  const int64_t nk = (a.nx + BK - 1) / BK;
+  const int64_t nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   constexpr bool DEEP = !(CPLX && sizeof(R) == 8);   // (complex double: two sets of four 16-byte units per tile spill)
   if constexpr (DEEP) {
     if (nk > 0) {
-      load_tiles(0, ra0, rb0);
+      load_tiles(kbeg, ra0, rb0);
       store_tiles(0, ra0, rb0);
-      if (nk > 1) load_tiles(BK, ra1, rb1);
+      if (nk > 1) load_tiles(kbeg + BK, ra1, rb1);
     }
     __syncthreads();
     for (int64_t t = 0; t < nk; t += 2) {
-      if (t + 2 < nk) load_tiles((t + 2) * BK, ra0, rb0);
+      if (t + 2 < nk) load_tiles(kbeg + (t + 2) * BK, ra0, rb0);
       compute(0);
       if (t + 1 < nk) store_tiles(1, ra1, rb1);
       __syncthreads();
       if (t + 1 >= nk) break;
-      if (t + 3 < nk) load_tiles((t + 3) * BK, ra1, rb1);
+      if (t + 3 < nk) load_tiles(kbeg + (t + 3) * BK, ra1, rb1);
       compute(1);
       if (t + 2 < nk) store_tiles(0, ra0, rb0);
       __syncthreads();
     }
   } else {
     int buf = 0;
-    if (nk > 0) { load_tiles(0, ra0, rb0); store_tiles(0, ra0, rb0); }
+    if (nk > 0) { load_tiles(kbeg, ra0, rb0); store_tiles(0, ra0, rb0); }
     __syncthreads();
     for (int64_t t = 0; t < nk; ++t) {
       const bool more = t + 1 < nk;
-      if (more) load_tiles((t + 1) * BK, ra0, rb0);
+      if (more) load_tiles(kbeg + (t + 1) * BK, ra0, rb0);
       if (buf == 0) compute(0); else compute(1);
       if (more) store_tiles(buf ^ 1, ra0, rb0);
       __syncthreads();
@@ -693,23 +697,64 @@ __global__ __launch_bounds__(256, 2) void dense_mfma16_kernel(DenseArgs a) {
           T y;
           if constexpr (CPLX) y = T{acc[0][tv][tr][r], acc[1][tv][tr][r]};
           else y = acc[0][tv][tr][r];
-          Y[i + (int64_t)v * a.ldy] = r1_apply<T>(a, y, i, v);
+          if (part) part[((int64_t)blockIdx.z * a.m + v) * a.ny + i] = y;     // [split][vector][row], summed by dense_splitk_reduce_t
+          else Y[i + (int64_t)v * a.ldy] = r1_apply<T>(a, y, i, v);
         }
       }
+}
+
+static int env_int_d(const char *name, int dflt);
+
+__device__ __forceinline__ double sum2(double x, double y) { return x + y; }
+__device__ __forceinline__ float sum2(float x, float y) { return x + y; }
+__device__ __forceinline__ c32 sum2(c32 x, c32 y) { return c32{x.re + y.re, x.im + y.im}; }
+__device__ __forceinline__ c64 sum2(c64 x, c64 y) { return c64{x.re + y.re, x.im + y.im}; }
+
+// the K splits of dense_mfma16_kernel summed in a fixed order, the rank-one epilogue applied
+template <typename T>
+__global__ __launch_bounds__(256) void dense_splitk_reduce_t(const T *__restrict__ part, int splits, int64_t ny, int m,
+                                                             T *__restrict__ Y, int64_t ldy, DenseArgs a) {
+  const int v = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ny; i += stride) {
+    T s = part[(int64_t)v * ny + i];
+    for (int z = 1; z < splits; ++z) s = sum2(s, part[((int64_t)z * m + v) * ny + i]);
+    Y[i + (int64_t)v * ldy] = r1_apply<T>(a, s, i, v);
+  }
 }
 
 template <typename T, typename R, bool CPLX, int TR, int TV>
 static int launch_mfma16(const DenseArgs &a) {
   Context &c = ctx();
-  dim3 grid((unsigned)((a.ny + 32 * TR - 1) / (32 * TR)), (unsigned)((a.m + 32 * TV - 1) / (32 * TV)));
+  const int64_t bx = (a.ny + 32 * TR - 1) / (32 * TR), by = (a.m + 32 * TV - 1) / (32 * TV);
+  // K splits until every CU has several workgroups (RLH_DENSE_WG_PER_CU, as the float32 kernels), at least 32 K steps each
+  static const int target = env_int_d("RLH_DENSE_WG_PER_CU", 8);
+  int64_t splits = ((int64_t)c.num_cu * target + bx * by - 1) / (bx * by);
+  const int64_t max_by_k = (a.nx + 16 * 32 - 1) / (16 * 32);
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits > 16) splits = 16;
+  while (splits > 1 && (size_t)splits * a.m * a.ny * sizeof(T) > kWorkspaceBytes) --splits;
+  if (splits < 1) splits = 1;
+  int64_t kchunk = ((a.nx + splits - 1) / splits + 15) / 16 * 16;
+  splits = (a.nx + kchunk - 1) / kchunk;
+  if (splits < 1) { splits = 1; kchunk = 16; }
+  T *part = splits > 1 ? (T *)c.work : nullptr;
+  dim3 grid((unsigned)bx, (unsigned)by, (unsigned)splits);
   if (a.a_kcontig) {
-    if (a.conj_a) hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, true, true, TR, TV>), grid, dim3(256), 0, c.stream, a);
-    else hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, true, false, TR, TV>), grid, dim3(256), 0, c.stream, a);
+    if (a.conj_a) hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, true, true, TR, TV>), grid, dim3(256), 0, c.stream, a, part, kchunk);
+    else hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, true, false, TR, TV>), grid, dim3(256), 0, c.stream, a, part, kchunk);
   } else {
-    if (a.conj_a) hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, false, true, TR, TV>), grid, dim3(256), 0, c.stream, a);
-    else hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, false, false, TR, TV>), grid, dim3(256), 0, c.stream, a);
+    if (a.conj_a) hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, false, true, TR, TV>), grid, dim3(256), 0, c.stream, a, part, kchunk);
+    else hipLaunchKernelGGL((dense_mfma16_kernel<T, R, CPLX, false, false, TR, TV>), grid, dim3(256), 0, c.stream, a, part, kchunk);
   }
   RLH_HIP(hipGetLastError());
+  if (splits > 1) {
+    int64_t nb = (a.ny + 255) / 256;
+    if (nb > 64) nb = 64;
+    hipLaunchKernelGGL((dense_splitk_reduce_t<T>), dim3((unsigned)nb, (unsigned)a.m), dim3(256), 0, c.stream, part, (int)splits, a.ny,
+                       a.m, (T *)a.Y, a.ldy, a);
+    RLH_HIP(hipGetLastError());
+  }
   return 0;
 }
 
@@ -818,12 +863,14 @@ static int dense_impl(const DenseArgs &a) {
     const bool ok = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.X)) & 15u) == 0 && (a.lda % EPU == 0) &&
                     (a.ldx % EPU == 0) && a.lda >= EPU && a.ldx >= EPU && a.nx > 0 && !env_int_d("RLH_DENSE_VALU", 0);
     if (ok) {
-      // 64 rows x 64 vectors per workgroup (measured at 20000 x 20000 x 128 fp64: 33 TF against 27 TF for 64 x 128 tiles,
-      // whose 313 workgroups leave the second round of the 256 CUs a quarter full, and 13 TF for the VALU kernel)
+      // 64 rows x 128 vectors per workgroup where there are more than 64 vectors -- every element of A is read ONCE -- with K
+      // split over gridDim.z until the chip is evenly filled (launch_mfma16): 20000 x 20000 x 128 fp64 in 1.91 / 1.95 ms =
+      // 53.7 / 52.5 TF, 62500 x 40000 53.6 / 53.2 TF (64 x 64 tiles, which read A twice: 49.7 / 47.3 TF with the K splits,
+      // 42.7 / 41.1 TF without: 626 workgroups on 512 resident slots left the second round a fifth full; 128 x 64 tiles
+      // 51.8 / 49.4 TF -- and two of their instantiations spilled: dropped).  RLH_DENSE_D_TILE=22: 64 x 64 tiles regardless.
       if constexpr (DT == RLH_D) {
-        const int tile = env_int_d("RLH_DENSE_D_TILE", 22);      // 22: 64 x 64, 24: 64 rows x 128 vectors, 42: 128 x 64 (tunable)
+        const int tile = env_int_d("RLH_DENSE_D_TILE", 24);
         if (tile == 24 && a.m > 64) return launch_mfma16<double, double, false, 2, 4>(a);
-        if (tile == 42) return launch_mfma16<double, double, false, 4, 2>(a);
         return launch_mfma16<double, double, false, 2, 2>(a);
       }
       if constexpr (DT == RLH_Z) return launch_mfma16<c64, double, true, 2, 2>(a);

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
     const WellMeta mt = meta[sb];
     const int ng = mt.width_ng >> 8;               // a multiple of 8, <= SLOT / (64 sizeof(T)) and <= 16 EPL LD
     // entries: values, and two 16-bit positions per register as stored (unpacked at use)
-    int64_t row[R];
+    int row[R];                                    // this thread's row of member r (-1: none), 32 bits: n < 2^31
     T v[R][WMAX];
     unsigned ixb[R][WMAX / 2];
     bool whole = true;                             // every member present has all its 1024 rows (workgroup-uniform)
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
         nmem = r + 1;
         whole = whole && mr.y == kWellRows;
       }
-      row[r] = tid < mr.y ? (int64_t)mr.x + tid : n_rows;
+      row[r] = tid < mr.y ? mr.x + tid : -1;
       unsigned px[WMAX];
       // (not for 16-byte elements: the second path costs complex128 six spilled registers, and scratch traffic would
       // sit in the same counter as the DMAs)
@@ -830,9 +830,9 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
           }
         }
         // (non-temporal stores: 1.107 against 1.140 ms with plain ones, variants taking turns in one process)
-        if constexpr ((DBG & 4) != 0) { if (ixb[r][0] == 0xfffffffeu) Y[row[r] + (int64_t)j * ldy] = acc; }
-        else if constexpr ((DBG & 8) != 0) { if (whole || row[r] < n_rows) Y[row[r] + (int64_t)j * ldy] = acc; }
-        else if (whole || row[r] < n_rows) stk_store(Y + row[r] + (int64_t)j * ldy, acc);
+        if constexpr ((DBG & 4) != 0) { if (ixb[r][0] == 0xfffffffeu) Y[(int64_t)row[r] + (int64_t)j * ldy] = acc; }
+        else if constexpr ((DBG & 8) != 0) { if (whole || row[r] >= 0) Y[(int64_t)row[r] + (int64_t)j * ldy] = acc; }
+        else if (whole || row[r] >= 0) stk_store(Y + (int64_t)row[r] + (int64_t)j * ldy, acc);
       }
     };
     // every wave is done with the previous stack's slots (its last vectors were read after the last barrier)
