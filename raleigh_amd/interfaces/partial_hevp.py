@@ -99,15 +99,21 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
         if inexact is not None and inexact.tol is None:
             inexact.tol = min(1e-6, max(1e-12, 0.01 * tol))
         try:
-            if inexact is not None and vectors is not None:
-                neg, pos = solver.inertia(vectors=lambda n_, nv, data_type: _with(make_vectors(n_, data_type=data_type), nv))
+            mk = (lambda n_, nv, data_type: _with(make_vectors(n_, data_type=data_type), nv)) if vectors is not None else None
+            if inexact is not None and type(which) is not tuple and not buckling:
+                # an integer `which` only asks whether both signs occur (one- or two-sided search): a short Lanczos run
+                # instead of the full count (a tenth of its cost; the counts below are then 0 / 1 flags, not numbers)
+                has_neg, has_pos = solver.signs(vectors=mk)
+                neg, pos = int(has_neg), int(has_pos)
+            elif inexact is not None:
+                neg, pos = solver.inertia(vectors=mk)
             else:
                 neg, pos = solver.inertia()
         except RuntimeError as err:
             if verb > -1:
                 print('%s' % err)
             return None, None, -1
-        if verb > -1:
+        if verb > -1 and (inexact is None or type(which) is tuple or buckling):
             print('positive eigenvalues: %d' % pos)
             print('negative eigenvalues: %d' % neg)
         if type(which) is tuple:

@@ -187,6 +187,6 @@ def test_config5_sharded_inexact_shift_invert_at_full_size(comm):
     lmd, x, status = partial_hevp(None, sigma=sigma, which=20, tol=1e-6, verb=-1, opt=opt, solver=sol, operator=op,
                                   vectors=lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm, offsets=off))
     assert status == 0 and len(lmd) >= 20
-    assert sol.inertia()[0] == below
+    assert sol.inertia(vectors=lambda nn, nv, data_type: ShardedVectors(nn, nv, data_type, comm=comm, offsets=off))[0] == below
     for e in exact[np.argsort(np.abs(exact - sigma))[:20]]:
         assert np.min(np.abs(lmd - e)) < 1e-10 * abs(e)
