@@ -155,3 +155,35 @@ def test_partial_hevp_inexact_shift_invert_generalized():
         assert np.min(np.abs(lmd - e)) < 1e-10 * abs(e)
     r = A @ x - (B @ x) * lmd
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-5 * np.abs(exact).max()
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.complex64])
+def test_single_precision_blocks(dtype):
+    """Blocks of float32 / complex64: the solve to 1e-4 (the Gram matrices the block is split by are only good to a few
+    float32 eps, so directions below 3e-3 of their block's largest are dropped) and the eigenvalues nearest the shift to
+    1e-5 (fp32 sigma class of SURVEY 8c)."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from raleigh_amd.interfaces import partial_hevp
+    from raleigh_amd.core.solver import Options
+    from raleigh_amd.algebra.hip.shift_invert import ShiftedOperator, IterativeSymmetricSolver, block_minres
+    from oracle.sparse import lap3d
+    A64 = sp.csr_matrix(lap3d(10, 10, 10, 1.0, 1.01, 1.02))
+    exact = np.linalg.eigvalsh(A64.toarray())
+    A = A64.astype(dtype)
+    n = A.shape[0]
+    sigma = float(0.5 * (exact[10] + exact[11]))
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal((8, n)).astype(dtype)
+    B, X = Vectors(b.copy()), Vectors(n, 8, data_type=dtype)
+    info = block_minres(ShiftedOperator(SparseSymmetricMatrix(A), sigma), B, X, tol=1e-4, max_iter=400)
+    assert info.converged
+    r = (A64 - sigma * sp.identity(n)) @ X.data().T.astype(np.complex128) - b.T
+    assert np.max(np.linalg.norm(r, axis=0) / np.linalg.norm(b, axis=1)) < 5e-4
+    np.random.seed(1)
+    sol = IterativeSymmetricSolver(dtype=dtype, pos_def=True, degree=6, ratio=20.0, tol=1e-5)
+    opt = Options()
+    opt.block_size = 16
+    lmd, x, status = partial_hevp(A, sigma=sigma, which=6, tol=1e-3, verb=-1, opt=opt, solver=sol)
+    assert status == 0
+    for e in exact[np.argsort(np.abs(exact - sigma))[:4]]:
+        assert np.min(np.abs(lmd - e)) < 1e-5 * abs(e)
