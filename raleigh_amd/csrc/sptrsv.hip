@@ -866,6 +866,10 @@ static int solve_chain_impl(int nops, rlh_sptrsv *const *ops, const int64_t *per
   {
     int occ = 0;                                               // resident workgroups per CU of this kernel
     RLH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trsv_pipeline_kernel<T>, 256, 0));
+    // (round 4's sweep of 1 / 2 / 3 / 4 resident workgroups per CU, one box: ILUT of lap3d 100^3 4.24 / 2.84 / 2.68 / 2.72 ms, config-3
+    // surrogate 5.39 / 3.13 / 3.12 / 3.43, lap3d 160^3 - / - / 7.42 / 6.68, SuperLU factors of lap3d 30^3 - / - / 2.06 / 1.96: no
+    // setting wins everywhere and nothing separates the two camps beforehand, so what the registers allow (4) stays;
+    // the pause between poll rounds, 1 / 2 / 4, changes nothing)
     int per_cu = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     const char *e = getenv("RLH_SPTRSV_WG_PER_CU");            // tunable
     if (e && *e && atoi(e) > 0) per_cu = atoi(e);
