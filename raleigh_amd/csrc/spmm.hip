@@ -2093,6 +2093,34 @@ static int csr_from_upper(rlh_csr_t *out, int dtype, int64_t n, const int64_t *i
   RLH_REQUIRE(bad_kind.load() != 1, "rlh_csr_create_upper: column index out of range in row %lld", (long long)bad_row.load());
   RLH_REQUIRE(bad_kind.load() != 2, "rlh_csr_create_upper: the column indices of row %lld are not sorted (or repeat)",
               (long long)bad_row.load());
+  // A caller that stores BOTH triangles of a Hermitian matrix (what SciPy users hold) has handed over the operator itself:
+  // if every entry below the diagonal is the conjugate of its mirror image above it -- checked entry by entry, one binary
+  // search each, on the host threads -- and the two triangles have equally many entries, nothing needs mirroring and no
+  // second copy of the matrix is allocated (lap3d 215^3: 0.2 s and 0.8 GB less).  Any mismatch: the upper triangle rules.
+  {
+    int64_t own_total = 0, mirrored_total = 0;
+    for (int64_t i = 0; i < n; ++i) { own_total += below[(size_t)i]; mirrored_total += cnt[(size_t)i + 1].load(std::memory_order_relaxed); }
+    const int64_t lower_total = indptr[n] - own_total;
+    if (lower_total > 0 && lower_total == mirrored_total) {
+      std::atomic<int> mismatch{0};
+      host_parallel(64, [&](int t, int nt) {
+        for (int64_t i = n * t / nt; i < n * (t + 1) / nt && !mismatch.load(std::memory_order_relaxed); ++i)
+          for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+            const int32_t j = indices[e];
+            if (j >= i) break;                                   // (sorted: the rest of the row is the upper part)
+            const int32_t *b0 = indices + indptr[j], *b1 = indices + indptr[j + 1];
+            const int32_t *f = std::lower_bound(b0, b1, (int32_t)i);
+            if (f == b1 || *f != (int32_t)i) { mismatch.store(1); break; }
+            const T up = conj_of(values[f - indices]);
+            if (memcmp(&up, &values[e], sizeof(T)) != 0) { mismatch.store(1); break; }
+          }
+      });
+      if (!mismatch.load()) {
+        clk.lap("both triangles given and consistent");
+        return rlh_csr_create(out, dtype, n, n, indptr, indices, values);
+      }
+    }
+  }
   std::vector<int64_t> rp((size_t)n + 1, 0);
   for (int64_t i = 0; i < n; ++i) {
     const int64_t mirrored = cnt[(size_t)i + 1].load(std::memory_order_relaxed);

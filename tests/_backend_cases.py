@@ -214,7 +214,24 @@ def sparse_case(golden_dir):
     opb = SparseSymmetricMatrix(B)
     opb.apply(x, y)
     assert rel(y.data(), g['lap_y']) < 1e-13
+    # ... and so is a lower triangle with an entry missing (both triangles given and CONSISTENT is the one case in which the
+    # library takes the matrix as it comes instead of mirroring its upper triangle)
+    C = sp.lil_matrix(A)
+    C[5, 4] = 0.0
+    C = sp.csr_matrix(C)
+    C.eliminate_zeros()
+    opc = SparseSymmetricMatrix(C)
+    opc.apply(x, y)
+    assert rel(y.data(), g['lap_y']) < 1e-13
     H = sp.csr_matrix(g['herm_dense'])
+    Hbad = sp.lil_matrix(H)
+    i, j = sp.tril(H, k=-1).nonzero()
+    Hbad[i[0], j[0]] = H[i[0], j[0]].conjugate()         # a lower entry that is NOT the conjugate of its mirror image
+    opzb = SparseSymmetricMatrix(sp.csr_matrix(Hbad))
+    xz0 = Vectors(g['herm_x'].copy())
+    yz0 = Vectors(H.shape[0], 3, data_type=np.complex128)
+    opzb.apply(xz0, yz0)
+    assert rel(yz0.data(), g['herm_y']) < 1e-13
     opz = SparseSymmetricMatrix(H)
     xz = Vectors(g['herm_x'].copy())
     yz = Vectors(H.shape[0], 3, data_type=np.complex128)
