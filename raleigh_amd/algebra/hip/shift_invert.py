@@ -248,6 +248,37 @@ def _block_minres(op, b, x, precond, tol, max_iter, work, drop, count_negative):
     return info
 
 
+def spectrum_upper_bound(op, make_vectors, n, dtype, steps=12):
+    """An upper bound of the spectrum of a Hermitian operator from `steps` Lanczos steps on one random vector:
+    theta_max + |beta_k s_k| (largest Ritz value plus the residual norm of its Ritz pair), the bound Chebyshev-filtered
+    eigensolvers use for the same purpose (Zhou & Saad); 5 % are added on top.  For operators that come without a matrix
+    (row-sharded ones), where no Gershgorin bound can be taken."""
+    v_prev, v, w = make_vectors(n, 1, dtype), make_vectors(n, 1, dtype), make_vectors(n, 1, dtype)
+    v.fill_random()
+    nrm = np.sqrt(abs(v.dots(v)[0]))
+    v.scale(np.array([nrm]))
+    alphas, betas = [], []
+    beta = 0.0
+    for j in range(steps):
+        op.apply(v, w)
+        if j > 0:
+            w.add(v_prev, -beta)
+        a = float(np.real(w.dots(v)[0]))
+        w.add(v, -a)
+        b = float(np.sqrt(abs(w.dots(w)[0])))
+        alphas.append(a)
+        betas.append(b)
+        if b <= 1e-14 * max(abs(a), 1.0):
+            break
+        v_prev, v, w = v, w, v_prev
+        v.scale(np.array([b]))
+        beta = b
+    k = len(alphas)
+    t = np.diag(alphas) + np.diag(betas[:k - 1], 1) + np.diag(betas[:k - 1], -1)
+    lam, vec = sla.eigh(t)
+    return 1.05 * (float(lam[-1]) + abs(betas[k - 1] * vec[-1, -1]))
+
+
 class IterativeSymmetricSolver:
     """(A - sigma B)^-1 by preconditioned block MINRES: the surface of the reference's SparseSymmetricSolver
     (raleigh/algebra/sparse_mkl.py:51-119: analyse / factorize / solve / inertia / size / data_type / sigma)
@@ -257,7 +288,7 @@ class IterativeSymmetricSolver:
     device operator with apply(x, y), size() and data_type() -- e.g. a ShardedSparseMatrix, with row-sharded
     blocks.  preconditioner: None, an operator with apply(x, y) (Hermitian positive definite, FIXED and
     linear), or 'chebyshev' (needs pos_def=True: a polynomial p(A) ~ A^-1 of the given degree on
-    [hi / ratio, hi], hi the Gershgorin bound or `hi=`): the right choice for a shift in the lower part of the
+    [hi / ratio, hi], hi the Gershgorin bound of the matrix, a Lanczos bound for a ready operator, or `hi=`): the right choice for a shift in the lower part of the
     spectrum of a positive definite A, where A - sigma I has few negative eigenvalues and p(A)(A - sigma I)
     is a cluster at 1 plus the few hundred eigenvalues below hi / ratio, which the block Krylov space absorbs.
     tol: bound on the relative residual (in the preconditioner's norm) of every column; None: 1e-10, or, inside
@@ -275,6 +306,7 @@ class IterativeSymmetricSolver:
             else preconditioner
         self._degree, self._ratio, self._hi = int(degree), float(ratio), hi
         self._op = self._opa = self._opb = self._pre = None
+        self._vectors = None
         self._work = {}
         self._neg = None
         self.solves = 0
@@ -282,8 +314,11 @@ class IterativeSymmetricSolver:
         self.columns_applied = 0        # operator applications, in vectors
         self.last = None
 
-    def analyse(self, a, sigma=0, b=None):
+    def analyse(self, a, sigma=0, b=None, vectors=None):
+        """vectors: factory ``f(n, nvec, data_type=)`` of the blocks the solver creates itself (the spectrum bound of a ready
+        operator, the inertia probe) -- row-sharded ones for a row-sharded operator."""
         from .sparse import SparseSymmetricMatrix
+        self._vectors = vectors
         self._matrix = None
         if hasattr(a, 'apply'):
             self._opa = a
@@ -313,10 +348,14 @@ class IterativeSymmetricSolver:
         from .precond import ChebyshevPreconditioner, gershgorin_upper_bound
         hi = self._hi
         if hi is None:
-            if self._matrix is None:
-                raise ValueError('hi= (an upper bound of the spectrum) is needed with a ready operator')
-            u = scs.triu(scs.csr_matrix(self._matrix), format='csr')
-            hi = gershgorin_upper_bound(u + scs.triu(u, 1).conj().T)
+            if self._matrix is None:              # a ready operator (e.g. row-sharded): a Lanczos bound from its own products
+                from .vectors import Vectors
+                mk = self._vectors if self._vectors is not None else (lambda n, nv, data_type: Vectors(n, nv, data_type=data_type))
+                hi = spectrum_upper_bound(self._opa, mk, self._n, self._dtype)
+            else:
+                u = scs.triu(scs.csr_matrix(self._matrix), format='csr')
+                hi = gershgorin_upper_bound(u + scs.triu(u, 1).conj().T)
+        self.hi = hi
         self._pre = ChebyshevPreconditioner(self._opa, hi, ratio=self._ratio, degree=self._degree)
 
     def _tol(self):
@@ -344,7 +383,7 @@ class IterativeSymmetricSolver:
         if self._neg is not None:
             return self._neg > 0, self._neg < self._n
         from .vectors import Vectors
-        make = vectors if vectors is not None else (lambda n, nv, data_type: Vectors(n, nv, data_type=data_type))
+        make = vectors or self._vectors or (lambda n, nv, data_type: Vectors(n, nv, data_type=data_type))
         k = min(8, self._n)
         b, x = make(self._n, k, data_type=self._dtype), make(self._n, k, data_type=self._dtype)
         b.fill_random()
@@ -360,7 +399,7 @@ class IterativeSymmetricSolver:
         if self._neg is None:
             from .vectors import Vectors
             k = 32 if probe is None else int(probe)
-            make = vectors if vectors is not None else (lambda n, nv, data_type: Vectors(n, nv, data_type=data_type))
+            make = vectors or self._vectors or (lambda n, nv, data_type: Vectors(n, nv, data_type=data_type))
             while True:
                 k = min(k, self._n)
                 b, x = make(self._n, k, data_type=self._dtype), make(self._n, k, data_type=self._dtype)

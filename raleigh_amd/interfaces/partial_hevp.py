@@ -57,7 +57,8 @@ def partial_hevp(A, B=None, T=None, buckling=False, sigma=0, which=6, tol=1e-4, 
             if solver.operator() is None:
                 if verb > -1:
                     print('setting up the iterative linear system solver...')
-                solver.analyse(operator if operator is not None else A, sigma, B)
+                mk0 = (lambda n_, nv, data_type: _with(make_vectors(n_, data_type=data_type), nv)) if vectors is not None else None
+                solver.analyse(operator if operator is not None else A, sigma, B, vectors=mk0)
                 solver.factorize()
             n, dtype, sigma = solver.size(), solver.data_type(), solver.sigma()
         else:

@@ -185,7 +185,7 @@ def main():
     from raleigh_amd.algebra.hip.shift_invert import IterativeSymmetricSolver
     op5 = ShardedSparseMatrix(A5, comm)
     mk5 = lambda nn, data_type: ShardedVectors(nn, 0, data_type, comm=comm)
-    sol5 = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=6, ratio=20.0, hi=gershgorin_upper_bound(A5))
+    sol5 = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=6, ratio=20.0)       # (hi: Lanczos bound on the sharded operator)
     calls_before = fake_lib_calls().get('rlh_sptrsv_solve_chain', 0)
     np.random.seed(1)
     lmd6, x6, status = partial_hevp(None, sigma=sigma5, which=(3, 3), tol=1e-7, verb=-1, vectors=mk5, operator=op5, solver=sol5)
@@ -193,6 +193,7 @@ def main():
     assert np.max(np.abs(np.sort(lmd6) - want5)) < 1e-10 * np.abs(exact5).max()
     assert fake_lib_calls().get('rlh_sptrsv_solve_chain', 0) == calls_before                  # no factors anywhere
     assert sol5.inertia() == (21, n5 - 21) and sol5.solves > 2
+    assert exact5[-1] < sol5.hi < 1.3 * exact5[-1]
     r6 = A5 @ x6 - x6 * lmd6
     assert np.max(np.linalg.norm(r6, axis=0)) < 1e-6 * np.abs(exact5).max()
 

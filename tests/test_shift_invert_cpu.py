@@ -187,3 +187,21 @@ def test_single_precision_blocks(dtype):
     assert status == 0
     for e in exact[np.argsort(np.abs(exact - sigma))[:4]]:
         assert np.min(np.abs(lmd - e)) < 1e-5 * abs(e)
+
+
+def test_spectrum_bound_of_a_ready_operator():
+    """A ready operator (no matrix to take a Gershgorin bound from): the upper end of the Chebyshev interval from twelve
+    Lanczos steps -- above the largest eigenvalue, within 30 % of it -- and the solve goes through."""
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    from raleigh_amd.algebra.hip.shift_invert import IterativeSymmetricSolver
+    A, exact = hermitian(9, np.complex128)
+    n = A.shape[0]
+    np.random.seed(3)
+    sol = IterativeSymmetricSolver(dtype=np.complex128, pos_def=True, degree=6, ratio=20.0)
+    sol.analyse(SparseSymmetricMatrix(A), 0.5 * (exact[6] + exact[7]))
+    sol.factorize()
+    assert exact[-1] < sol.hi < 1.3 * exact[-1]
+    b, x = Vectors(n, 5, data_type=np.complex128), Vectors(n, 5, data_type=np.complex128)
+    b.fill_random()
+    sol.solve(b, x)
+    assert sol.last.converged and sol.inertia() == (7, n - 7)
