@@ -103,6 +103,7 @@ struct rlh_csr {
   void *wide_idx;          // device: 16-byte pieces of 8 positions, [chunk][row]
   void *wide_vals;         // device: 16-byte pieces of values, [chunk][piece][row]
   int wide_gmax;           // largest number of staging groups of a block
+  int wide_k;              // rows per thread of the interleaved layout: 2 where consecutive rows share their column pattern (FE nodes)
   std::vector<int32_t> wide_order, wide_maxcol;
   std::vector<WideSched> wide_scheds;
 };

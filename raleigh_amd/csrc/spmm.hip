@@ -2199,7 +2199,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->well_split_at = -1; h->well_sched_part[0] = h->well_sched_part[1] = nullptr;
   h->well_sched_part_len[0] = h->well_sched_part_len[1] = 0; h->well_grid_part[0] = h->well_grid_part[1] = 0;
   h->wide_blocks = 0; h->wide_meta = nullptr; h->wide_gsrc = nullptr; h->wide_idx = nullptr; h->wide_vals = nullptr;
-  h->wide_gmax = 0; h->n_slices = 0; h->padded = 0; h->device_bytes = 0; h->well_wmax = 0;
+  h->wide_gmax = 0; h->wide_k = 1; h->n_slices = 0; h->padded = 0; h->device_bytes = 0; h->well_wmax = 0;
   // Layout (RLH_SPMM_FORMAT=sell|well|wide overrides the choice and the locality test; read per
   // handle so tests can cover all three): rows of at most 8 entries of a real type -> the 1024-row
   // windowed layout; otherwise, or when that one does not qualify -> the 256-row interleaved

@@ -56,6 +56,25 @@ int wide_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const 
   if ((int64_t)gmax * kWideGroup * wide_stride(wide_min_nv(h->dtype), es) + 2 * kWideHeader > kWideLdsBytes) return 0;
   if (gmax * 4 > kWideHeader || wmax > 8 * 32767) return 0;
   if (!force && staged * 10 > slots * 9) return 0;      // too little column locality for the staging to pay
+  // Rows that share their column pattern with the row after them -- the unknowns of a node of a finite-element model: every
+  // degree of freedom of a node couples to every degree of freedom of its neighbours -- are given to ONE thread in pairs: the
+  // pair's entries are one position and two values, and the staged x values of an entry, which are what bounds the kernel
+  // on long rows (every stored entry reads its NV staged values out of the LDS: profiles/r02_spmm_wide.txt), are read once
+  // for both rows.  All complete pairs (2 i, 2 i + 1) of the matrix must qualify; real types; RLH_WIDE_PAIR=0: never.
+  int K = 1;
+  if ((h->dtype == RLH_S || h->dtype == RLH_D) && env_int("RLH_WIDE_PAIR", 1) != 0 && h->nnz >= 16 * n) {
+    std::atomic<int> differ{0};
+    host_parallel(64, [&](int t, int nt) {
+      const int64_t pairs = n / 2;
+      for (int64_t q = pairs * t / nt; q < pairs * (t + 1) / nt && !differ.load(std::memory_order_relaxed); ++q) {
+        const int64_t r = 2 * q, la = indptr[r + 1] - indptr[r], lb = indptr[r + 2] - indptr[r + 1];
+        if (la != lb || memcmp(indices + indptr[r], indices + indptr[r + 1], (size_t)la * sizeof(int32_t)) != 0) differ.store(1);
+      }
+    });
+    if (!differ.load()) K = 2;
+  }
+  h->wide_k = K;
+  const int TPS = kWideRows / K;                  // threads per set of vectors = row groups of a block
   std::vector<WideMeta> meta((size_t)nblocks);
   int64_t eoff = 0, goff = 0;
   for (int64_t b = 0; b < nblocks; ++b) {
@@ -67,7 +86,8 @@ int wide_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const 
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
   std::vector<int32_t> gsrc((size_t)goff);
   const int64_t nchunks = eoff + kWidePadChunks;  // padding: the kernel's prefetch runs ahead of the last block's chunks
-  std::vector<char> idx((size_t)nchunks * kWideRows * 16, 0);
+  // K = 2: positions [chunk][row pair], values [chunk][row of the pair][piece][row pair]
+  std::vector<char> idx((size_t)nchunks * TPS * 16, 0);
   std::vector<char> vals((size_t)nchunks * VP * kWideRows * 16, 0);
   parallel_blocks(nblocks, [&](int64_t b) {
     const std::vector<Win> &ws = wins[b];
@@ -75,20 +95,24 @@ int wide_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices, const 
     const int64_t r0 = b * kWideRows;
     for (int l = 0; l < kWideRows; ++l) {
       const int64_t r = r0 + l;
-      const int64_t p = r < n ? indptr[r] : 0, len = r < n ? indptr[r + 1] - p : 0;
+      const int lt = l / K, lk = l % K;             // thread of the set, row of its group
+      // (a row past the end of the matrix: the slots of its pair partner's positions with value 0)
+      const int64_t rp_ = r < n ? r : (K > 1 && r - lk < n ? r - lk : -1);
+      const int64_t p = rp_ >= 0 ? indptr[rp_] : 0, len = rp_ >= 0 ? indptr[rp_ + 1] - p : 0;
+      const bool real_row = r < n;
       // padding slots carry value 0 and the position of the row's own first entry, so that they
       // only ever touch a column the row references (0 * Inf of a foreign column would be NaN)
       const uint16_t padpos = len > 0 ? (uint16_t)staged_position(ws, indices[p]) : 0;
       for (int t = 0; t < meta[b].nchunks * 8; ++t) {
         const int64_t q = meta[b].eoff + t / 8;
         const int tt = t % 8;
-        uint16_t *pi = reinterpret_cast<uint16_t *>(idx.data() + ((size_t)q * kWideRows + l) * 16) + tt;
-        if (t < len) {
-          *pi = (uint16_t)staged_position(ws, indices[p + t]);
-          char *pv = vals.data() + (((size_t)q * VP + tt / VPG) * kWideRows + l) * 16 + (size_t)(tt % VPG) * es;
+        if (lk == 0) {
+          uint16_t *pi = reinterpret_cast<uint16_t *>(idx.data() + ((size_t)q * TPS + lt) * 16) + tt;
+          *pi = t < len ? (uint16_t)staged_position(ws, indices[p + t]) : padpos;
+        }
+        if (t < len && real_row) {
+          char *pv = vals.data() + ((((size_t)q * K + lk) * VP + tt / VPG) * TPS + lt) * 16 + (size_t)(tt % VPG) * es;
           memcpy(pv, values + (size_t)(p + t) * es, (size_t)es);
-        } else {
-          *pi = padpos;
         }
       }
     }

@@ -1240,6 +1240,52 @@ def test_spmm_wide_rows_fe_like(monkeypatch, key, m, nv):
     assert np.array_equal(X.data(), x)
 
 
+@pytest.mark.parametrize('key', ['d', 's'])
+@pytest.mark.parametrize('odd', [False, True])
+def test_spmm_wide_row_pairs(monkeypatch, key, odd):
+    """Rows that share their column pattern pairwise (the two unknowns of a node) go to one thread as a pair -- one
+    position, two values per entry, the staged x values read once for both (wide_spmm_kernel<..., K = 2>): bit for bit the
+    result of the one-row-per-thread layout (RLH_WIDE_PAIR=0), plain and fused Chebyshev forms, an odd number of rows
+    (the last row has no partner), and a matrix whose rows do NOT pair (one entry removed) takes the other layout."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import fe_surrogate
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    A = sp.csr_matrix(fe_surrogate(grid=(9, 11, 13), dof=2).astype(DT[key]))
+    if odd:
+        A = sp.csr_matrix(A[:-1, :-1])
+    n = A.shape[0]
+    m = 19
+    rng = np.random.default_rng(5)
+    x, p0, b0 = rnd((m, n), key, rng), rnd((m, n), key, rng), rnd((m, n), key, rng)
+    X, B = Vectors(x), Vectors(b0)
+    results = []
+    for pair in ('1', '0'):
+        monkeypatch.setenv('RLH_WIDE_PAIR', pair)
+        op = CsrOperator(A)
+        assert op.layout()[0] == 'wide'
+        Y, P = Vectors(n, m, data_type=DT[key]), Vectors(p0.copy())
+        Y.fill(np.full((m, n), np.nan, dtype=DT[key]))
+        op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+        op.cheb_step_ptr(m, X, P, B, 1.3, -0.3, -0.7)
+        results.append((Y.data(), P.data()))
+    ref = (A.astype(np.float64) @ x.T.astype(np.float64)).T
+    assert cases.rel(results[0][0], ref) < (3e-6 if key == 's' else 1e-13)
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    # one entry less in one row: its pair no longer shares the pattern, the layout falls back to one row per thread
+    monkeypatch.setenv('RLH_WIDE_PAIR', '1')
+    C = sp.lil_matrix(A)
+    r = 200
+    c = int(A[r].indices[3])
+    C[r, c] = 0.0
+    C[c, r] = 0.0
+    C = sp.csr_matrix(C)
+    C.eliminate_zeros()
+    opc = CsrOperator(C)
+    Y = Vectors(n, m, data_type=DT[key])
+    opc.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+    assert cases.rel(Y.data(), (C.astype(np.float64) @ x.T.astype(np.float64)).T) < (3e-6 if key == 's' else 1e-13)
+
+
 def test_spmm_wide_padding_never_touches_foreign_columns(monkeypatch):
     """A non-finite entry of x in a column a row does not reference must not reach that row
     (padding slots point at the row's own first entry): the reference CSR product only touches
