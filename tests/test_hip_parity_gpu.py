@@ -687,6 +687,33 @@ def test_spmm_stacked_blocks_cut_plane_by_plane(monkeypatch, key, m):
     assert np.array_equal(Y.data(), y) if key == 'd' else cases.rel(Y.data(), y) < tol
 
 
+def test_plane_aligned_stacks_repeat_at_config5_size(monkeypatch):
+    """The stacks of BASELINE config 5's operator (126^3, complex128: row blocks cut plane by plane, EVERY member shorter than
+    1024 rows, so every wait of the LDS-DMA ring is a counted one on a stack with idle lanes): 300 products of 64 vectors, each
+    bit for bit the first (a miscounted wait is a race that shows once in thousands of stacks), the first against the
+    interleaved kernel of the same handle."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import hermitian_lap3d_rows
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.delenv('RLH_SPMM_STACK', raising=False)
+    N, m = 126, 64
+    n = N ** 3
+    op = CsrOperator(hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n))
+    assert op.stacks()[0] == 63 * 16
+    X, Y = Vectors(n, m, data_type=np.complex128), Vectors(n, m, data_type=np.complex128)
+    np.random.seed(11)
+    X.fill_random()
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+    first = Y.data()
+    for rep in range(300):
+        op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+        if rep % 50 == 49:                              # (the launches in between keep the queue full)
+            assert np.array_equal(Y.data(), first), rep
+    monkeypatch.setenv('RLH_SPMM_STACK', '0')
+    op.apply_ptr(m, X.data_ptr(), X.ld(), Y.data_ptr(), Y.ld())
+    assert cases.rel(Y.data(), first) < 1e-13
+
+
 @pytest.mark.parametrize('key', ['d', 's', 'z'])
 def test_spmm_stacked_blocks_with_halo(monkeypatch, key):
     """The stacked layout on a row shard (rlh_spmm_part): the LDS-DMA kernel fetches the pieces right of the own / halo
