@@ -291,6 +291,40 @@ int rlh_sptrsv_solve_chain(int nops, const rlh_sptrsv_t *ops, const int64_t *d_p
                            void *X, int64_t ldx);
 int rlh_sptrsv_destroy(rlh_sptrsv_t t);
 
+/* ---- symmetric indefinite factorisation for the direct shift-invert operator
+ *      (sparse_mkl.py:51-119 SparseSymmetricSolver -> mkl_wrap.py:354-489 class ParDiSo: PARDISO
+ *      mtype -2 / -4 (2 / 4 when pos_def), phases 11 / 22 / 33, inertia from iparm[21], iparm[22])
+ * rlh_ldlt_factor: P A P^T = L D L^H of a real symmetric / Hermitian matrix given by its UPPER
+ * triangle (entries below the diagonal are ignored) as 0-based CSR in HOST memory (dtype RLH_D or
+ * RLH_Z); runs on the host (no GPU needed).  perm: NULL -> own minimum-degree ordering, else
+ * perm[new] = old.  D has 1 x 1 and 2 x 2 blocks chosen by threshold partial pivoting among the
+ * fully summed variables of a front (pivot_threshold u in [0, 0.5]: 0.01 is the usual choice, 0
+ * = no pivoting, for positive definite matrices); variables with no acceptable pivot are delayed
+ * to the parent front.  perturb: a pivot below perturb * (largest entry of A in its column) is
+ * taken for zero: such a pivot is replaced and counted (info[3]) -- the matrix is numerically
+ * singular.
+ * rlh_ldlt_info: info[0] entries of L, [1] negative and [2] positive eigenvalues of D (the
+ * inertia of A), [3] perturbed pivots, [4] 2 x 2 pivots, [5] delayed pivots, [6] largest front,
+ * [7] supernodes, [8] multiply-adds (estimate), [9] pivots forced at a root.
+ * rlh_ldlt_get: L strictly lower (unit diagonal implied) as CSR in PIVOT order; diag[k] = D[k, k];
+ * subdiag[k] = D[k + 1, k] where block[k] == 1 (first row of a 2 x 2 pivot; block 2 = second row,
+ * 0 = 1 x 1 pivot); order[k] = the row of A eliminated k-th, so that with c[k] = b[order[k]]
+ * the solution of A x = b is x[order[k]] = (L^-H D^-1 L^-1 c)[k].  Any pointer may be NULL. */
+#define RLH_LDLT_INFO 10
+typedef struct rlh_ldlt *rlh_ldlt_t;
+int rlh_ldlt_factor(rlh_ldlt_t *f, int dtype, int64_t n, const int64_t *indptr,
+                    const int32_t *indices, const void *values, const int64_t *perm,
+                    double pivot_threshold, double perturb);
+int rlh_ldlt_info(rlh_ldlt_t f, int64_t *info);
+int rlh_ldlt_get(rlh_ldlt_t f, int64_t *indptr, int32_t *indices, void *values, void *diag,
+                 void *subdiag, int8_t *block, int64_t *order);
+int rlh_ldlt_destroy(rlh_ldlt_t f);
+/* X <- D^-1 X for the block diagonal D of such a factorisation, on a column-major n x m block in
+ * DEVICE memory (PARDISO phase 332): d_coef holds two entries per row (DEVICE, the block's dtype):
+ * X'[i] = coef[2i] X[i] + coef[2i+1] X[i + d_shift[i]], d_shift[i] in {-1, 0, +1} (DEVICE int32). */
+int rlh_bdiag_solve(int dtype, int64_t n, const void *d_coef, const int32_t *d_shift, int64_t m,
+                    void *X, int64_t ldx);
+
 /* ---- K12: dense operator (dense_numpy.py:153-175; dense_cublas.py:732-776)
  * A: DEVICE, M x N, row-major (order 0, numpy C_CONTIGUOUS, lda >= N) or
  * column-major (order 1, F_CONTIGUOUS, lda >= M).

@@ -85,6 +85,11 @@ SIGNATURES = {
     'rlh_factors_nnz': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     'rlh_factors_get': [_p, _int, _p, _p, _p],
     'rlh_factors_destroy': [_p],
+    'rlh_ldlt_factor': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, _p, ctypes.c_double, ctypes.c_double],
+    'rlh_ldlt_info': [_p, _p],
+    'rlh_ldlt_get': [_p, _p, _p, _p, _p, _p, _p, _p],
+    'rlh_ldlt_destroy': [_p],
+    'rlh_bdiag_solve': [_int, _i64, _p, _p, _i64, _p, _i64],
     'rlh_sptrsv_create': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, _int, _int],
     'rlh_sptrsv_info': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     'rlh_sptrsv_solve_chain': [_int, _p, _p, _p, _i64, _p, _i64, _p, _i64],

@@ -1,9 +1,10 @@
 """Operators adjacent to the hot path whose FACTORISATION runs on the host.
 
 The reference's shift-invert operator is PARDISO on the host (raleigh/algebra/sparse_mkl.py:51-119).
-Here SuperLU factorises A - sigma B once on the host; every solve then runs on the device
-(`TriangularChain`: the factors and SuperLU's permutations, one persistent launch on the whole
-n x m block in HBM), so a solver iteration moves no block across PCIe.  `HostOperator` adapts a
+Here the library's own symmetric indefinite factorisation (`ldlt.py`: P A P^T = L D L^H, 1 x 1 / 2 x 2
+pivots, inertia from D) runs once on the host; every solve then runs on the device (`SymmetricSolve`:
+L, D^-1 and L^H on the whole n x m block in HBM), so a solver iteration moves no block across PCIe.
+`method='superlu'` keeps the earlier rounds' unsymmetric SuperLU factors (`TriangularChain`).  `HostOperator` adapts a
 caller's own host operator (two block transfers per application: the caller's choice, never a
 stand-in for a HIP kernel -- every Vectors operation still runs in librlhip.so).
 """
@@ -37,19 +38,32 @@ def _lib_error():
 
 
 class SparseSymmetricSolver:
-    """LU of A - sigma B (counterpart of sparse_mkl.py:51-119: PARDISO there, SuperLU here).
+    """Factorisation of A - sigma B (counterpart of sparse_mkl.py:51-119 / mkl_wrap.py:354-489: PARDISO there).
 
-    The factorisation runs once on the host, without pivoting in symmetric mode, so that the signs
-    of diag(U) give the inertia the caller needs to map `which` (partial_hevp.py:172-194).  The
-    SOLVES run on the device (`device=True`, the default): the factors L, U and SuperLU's row /
-    column permutations become a TriangularChain (level-scheduled triangular solves on the whole
-    n x m block in HBM, algebra/hip/precond.py), so a solver iteration moves no block across PCIe.
-    `device=False` keeps the host solve (two block transfers per application), which is what the
-    first round shipped."""
+    method='ldlt' (default): P (A - sigma B) P^T = L D L^H by the library's multifrontal factorisation on the host
+    (one triangle, 1 x 1 and 2 x 2 pivots with delayed pivoting: saddle-point matrices and shifts that leave zeros
+    on the diagonal factorise; `pos_def=True` switches the pivoting off like PARDISO's mtype 2 / 4); the inertia the
+    caller needs to map `which` (partial_hevp.py:172-194) is read off D.  A numerically singular matrix (a pivot
+    had to be perturbed) raises at factorize() like the reference's "near singular matrix?" exit.
+    method='superlu': SuperLU's unsymmetric LU in symmetric mode (both triangles; the inertia from diag(U) only
+    when SuperLU kept the symmetric pivot order).
 
-    def __init__(self, dtype=np.float64, pos_def=False, device=True):
+    The SOLVES run on the device (`device=True`, the default): the factors become sparse triangular operators on
+    the whole n x m block in HBM (algebra/hip/ldlt.py SymmetricSolve, algebra/hip/precond.py TriangularChain), so a
+    solver iteration moves no block across PCIe.  `device=False` solves on the host (two block transfers per
+    application; SuperLU factors only)."""
+
+    def __init__(self, dtype=np.float64, pos_def=False, device=True, method='ldlt', pivot_threshold=0.01):
+        if method not in ('ldlt', 'superlu'):
+            raise ValueError('method must be ldlt or superlu')
+        if method == 'ldlt' and not device:
+            raise ValueError('the L D L^H factors are applied on the device: device=False needs method=superlu')
         self._dtype = dtype
         self._lu = None
+        self._factors = None
+        self._method = method
+        self._pos_def = bool(pos_def)
+        self._threshold = 0.0 if pos_def else float(pivot_threshold)
         self._device = bool(device)
         self._chain = None
         self._work = None
@@ -65,6 +79,17 @@ class SparseSymmetricSolver:
         self._sigma = sigma
 
     def factorize(self):
+        self._chain = None
+        if self._method == 'ldlt':
+            from .ldlt import ldlt
+            try:
+                f = ldlt(self._a, pivot_threshold=self._threshold)
+            except _lib_error() as e:
+                raise RuntimeError('factorization failed (%s)' % e)
+            if f.info['perturbed'] or (self._pos_def and f.info['negative']):
+                raise RuntimeError('factorization failed (near singular matrix?)')
+            self._factors = f
+            return
         try:
             self._lu = sla.splu(self._a, permc_spec='MMD_AT_PLUS_A', diag_pivot_thresh=0.0,
                                 options=dict(SymmetricMode=True))
@@ -79,6 +104,9 @@ class SparseSymmetricSolver:
         dtype = np.dtype(self._dtype if dtype is None else dtype).type
         if self._chain is None:
             self._chain = {}
+        if dtype not in self._chain and self._method == 'ldlt':
+            from .ldlt import SymmetricSolve
+            self._chain[dtype] = SymmetricSolve(self._factors, dtype)
         if dtype not in self._chain:
             from .precond import TriangularChain
             lu = self._lu
@@ -95,7 +123,7 @@ class SparseSymmetricSolver:
             try:
                 chain = self._device_chain(b.data_type())
             except _lib_error() as e:
-                if 'memory' not in str(e).lower():
+                if 'memory' not in str(e).lower() or self._method == 'ldlt':
                     raise                       # (a missing library or GPU is an error, never a reason to solve on the host)
                 # factors that do not fit next to the blocks in HBM: the host solve below, loudly
                 import warnings
@@ -126,13 +154,16 @@ class SparseSymmetricSolver:
         self.solve(b, x)
 
     def inertia(self):
-        """(negative, positive) eigenvalue counts of A - sigma B from the signs of diag(U).
+        """(negative, positive) eigenvalue counts of A - sigma B: from D of the L D L^H factors (1 x 1 pivots by
+        sign, 2 x 2 pivots by determinant and trace), or -- method='superlu' -- from the signs of diag(U), which is
 
-        Only valid when SuperLU kept the symmetric pivot order (perm_r == perm_c), so that
+        only valid when SuperLU kept the symmetric pivot order (perm_r == perm_c), so that
         U = D L^H: `diag_pivot_thresh=0` still interchanges rows off an exactly zero diagonal
         (saddle-point or unluckily shifted matrices), and then the sign count is not the inertia.
         That case, and a zero pivot, raise -- partial_hevp maps them to status -1 like the
         reference's "factorization too inaccurate" exit (partial_hevp.py:147-156)."""
+        if self._method == 'ldlt':
+            return self._factors.inertia()
         lu = self._lu
         if not np.array_equal(lu.perm_r, lu.perm_c):
             raise RuntimeError('unsymmetric pivoting in the factorization of A - sigma B: inertia unavailable, '
@@ -151,3 +182,7 @@ class SparseSymmetricSolver:
 
     def sigma(self):
         return self._sigma
+
+    def factors(self):
+        """The SymmetricFactors of method='ldlt' (None before factorize())."""
+        return self._factors

@@ -30,7 +30,7 @@ class TriangularChain:
 
     def __init__(self, factors, dtype, perm_in=None, perm_out=None):
         import scipy.sparse as scs
-        L = _lib.lib()
+        L = self._L = _lib.lib()                          # (the handles belong to THIS library object)
         self._dtype = np.dtype(dtype).type
         self._code = _lib.dtype_code(self._dtype)
         self._ops = []
@@ -95,7 +95,7 @@ class TriangularChain:
         ops, self._ops = getattr(self, '_ops', []), []
         for h in ops:
             try:
-                _lib.library().rlh_sptrsv_destroy(h)
+                self._L.rlh_sptrsv_destroy(h)
             except Exception:
                 pass
 
@@ -118,7 +118,7 @@ class TriangularChain:
         if n != self._n:
             raise ValueError('Factors and vectors dimensions incompatible')
         pin, pout = self._perms
-        _lib.check(_lib.lib().rlh_sptrsv_solve_chain(
+        _lib.check(self._L.rlh_sptrsv_solve_chain(
             len(self._ops), self._arr, pin.ptr if pin else None, pout.ptr if pout else None, m,
             b.data_ptr(), b.ld(), x.data_ptr(), x.ld()))
 

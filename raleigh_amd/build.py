@@ -18,6 +18,7 @@ LIBDIR = os.path.join(PKG, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'librlhip.so')
 SOURCES = ['context', 'gram', 'update', 'spmm', 'spmm_wide_build', 'spmm_wide_s', 'spmm_wide_d', 'spmm_wide_c',
            'spmm_wide_z', 'sptrsv', 'dense']
+HOST_SOURCES = ['ldlt_host']        # plain C++ (host only): compiled by the same driver, no offload
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
 
@@ -28,7 +29,7 @@ def source_hash():
     """sha256 over the compile flags and every file the library is built from (file name + bytes)."""
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
     files.append(os.path.join(ROOT, 'include', 'rlhip.h'))
-    h = hashlib.sha256(' '.join(FLAGS + SOURCES).encode())
+    h = hashlib.sha256(' '.join(FLAGS + SOURCES + HOST_SOURCES).encode())
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, 'rb') as fh:
@@ -58,9 +59,11 @@ def build_library(force=False, verbose=False):
     inc = ['-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
     def compile_one(name):
-        src = os.path.join(CSRC, name + '.hip')
+        host = name in HOST_SOURCES
+        src = os.path.join(CSRC, name + ('.cpp' if host else '.hip'))
         obj = os.path.join(objdir, name + '.o')
-        cmd = [hipcc] + FLAGS + inc + ['-c', src, '-o', obj]
+        flags = ['-x', 'c++', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'include')] + [f for f in FLAGS if not f.startswith('--offload-arch')] if host else FLAGS
+        cmd = [hipcc] + flags + inc + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
@@ -68,8 +71,8 @@ def build_library(force=False, verbose=False):
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES) + len(HOST_SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES + HOST_SOURCES))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -1162,6 +1162,37 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
   return 0;
 }
 
+
+// ------------------------------------------------------------------ block diagonal of an L D L^H factorisation
+// X <- D^-1 X in place: the thread of the FIRST row of a 2 x 2 pivot writes both of its rows (it is the only one that
+// reads them), the thread of the second row leaves.
+template <typename T>
+__global__ void __launch_bounds__(256) bdiag_solve_kernel(int64_t n, const T *__restrict__ coef, const int32_t *__restrict__ shift,
+                                                          T *X, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int s = shift[i];
+  if (s < 0) return;
+  T *x = X + (int64_t)blockIdx.y * ldx;
+  const T xi = x[i];
+  if (s == 0) {
+    x[i] = mul_of(coef[2 * i], xi);
+    return;
+  }
+  const T xj = x[i + 1];
+  x[i] = add_of(mul_of(coef[2 * i], xi), mul_of(coef[2 * i + 1], xj));
+  x[i + 1] = add_of(mul_of(coef[2 * i + 2], xj), mul_of(coef[2 * i + 3], xi));
+}
+
+template <int DT>
+static int bdiag_solve_impl(int64_t n, const void *coef, const int32_t *shift, int64_t m, void *X, int64_t ldx) {
+  using T = typename DType<DT>::T;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)m);
+  hipLaunchKernelGGL(bdiag_solve_kernel<T>, grid, dim3(256), 0, ctx().stream, n, (const T *)coef, shift, (T *)X, ldx);
+  RLH_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace rlh
 
 using namespace rlh;
@@ -1276,6 +1307,21 @@ int rlh_sptrsv_destroy(rlh_sptrsv_t t) {
   }
   delete t;
   return 0;
+}
+
+int rlh_bdiag_solve(int dtype, int64_t n, const void *d_coef, const int32_t *d_shift, int64_t m, void *X, int64_t ldx) {
+  if (int rc = require_ready()) return rc;
+  RLH_REQUIRE(dtype_valid(dtype), "rlh_bdiag_solve: unknown dtype %d", dtype);
+  RLH_REQUIRE(n >= 0 && m >= 0 && m <= 65535, "rlh_bdiag_solve: bad sizes");
+  if (n == 0 || m == 0) return 0;
+  RLH_REQUIRE(d_coef && d_shift && X && ldx >= n, "rlh_bdiag_solve: bad arguments");
+  switch (dtype) {
+    case RLH_S: return bdiag_solve_impl<RLH_S>(n, d_coef, d_shift, m, X, ldx);
+    case RLH_D: return bdiag_solve_impl<RLH_D>(n, d_coef, d_shift, m, X, ldx);
+    case RLH_C: return bdiag_solve_impl<RLH_C>(n, d_coef, d_shift, m, X, ldx);
+    case RLH_Z: return bdiag_solve_impl<RLH_Z>(n, d_coef, d_shift, m, X, ldx);
+  }
+  return 1;
 }
 
 }  // extern "C"

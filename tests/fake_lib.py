@@ -375,6 +375,32 @@ class FakeLib:
     def rlh_factors_destroy(self, *a):
         return self._real().rlh_factors_destroy(*a)
 
+    def rlh_ldlt_factor(self, *a):
+        rc = self._real().rlh_ldlt_factor(*a)
+        if rc:
+            self._err = self._real().rlh_last_error()
+        return rc
+
+    def rlh_ldlt_info(self, *a):
+        return self._real().rlh_ldlt_info(*a)
+
+    def rlh_ldlt_get(self, *a):
+        return self._real().rlh_ldlt_get(*a)
+
+    def rlh_ldlt_destroy(self, *a):
+        return self._real().rlh_ldlt_destroy(*a)
+
+    def rlh_bdiag_solve(self, code, n, coef, shift, m, X, ldx):
+        self._count('rlh_bdiag_solve')
+        if n == 0 or m == 0:
+            return 0
+        c = _flat(coef, _DT[code], 2 * n).reshape(n, 2)
+        s = _flat(shift, np.int32, n)
+        x = _block(X, code, n, m, ldx)
+        old = x.copy()
+        x[:, :] = old * c[:, 0] + old[:, np.arange(n) + s] * np.where(s != 0, c[:, 1], 0)
+        return 0
+
     def rlh_sptrsv_create(self, ph, code, n, indptr, indices, values, lower, unit):
         ip = _flat(indptr, np.int64, n + 1).copy()
         nnz = int(ip[-1])

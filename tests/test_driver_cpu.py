@@ -216,10 +216,11 @@ def test_complex_hermitian_shift_invert_config5_shape():
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-5
 
 
-def test_inertia_refuses_unsymmetric_pivoting():
-    """An indefinite matrix with a zero diagonal entry makes SuperLU interchange rows even with
-    diag_pivot_thresh = 0: diag(U) then has the wrong signs, so the solver must refuse to report an
-    inertia (and partial_hevp must return status -1) instead of silently mapping `which` wrongly."""
+def test_inertia_with_a_zero_diagonal_entry():
+    """An indefinite matrix with a zero diagonal entry: SuperLU interchanges rows even with diag_pivot_thresh = 0,
+    diag(U) then has the wrong signs, so method='superlu' must refuse to report an inertia.  The L D L^H factors
+    (default) take a 2 x 2 pivot there (what PARDISO's mtype -2 does, mkl_wrap.py:354-384): the inertia is exact and
+    partial_hevp maps `which` correctly."""
     import scipy.sparse as sp
     from raleigh_amd.algebra.hip.host_ops import SparseSymmetricSolver
     from raleigh_amd.interfaces import partial_hevp
@@ -227,18 +228,29 @@ def test_inertia_refuses_unsymmetric_pivoting():
     d = np.linspace(1.0, 3.0, n)
     d[0] = 0.0                      # zero pivot in the first elimination step
     A = sp.diags([np.ones(n - 1), d, np.ones(n - 1)], [-1, 0, 1], format='csr')
-    solver = SparseSymmetricSolver()
+    ev = np.linalg.eigvalsh(A.toarray())
+    solver = SparseSymmetricSolver(method='superlu')
     solver.analyse(A, 0.0)
     solver.factorize()
     with pytest.raises(RuntimeError):
         solver.inertia()
-    lmd, x, status = partial_hevp(A, sigma=0.0, which=3, verb=-1)
+    lmd, x, status = partial_hevp(solver, which=3, verb=-1)
     assert status == -1 and lmd is None
-    # a definite shift of the same matrix factorises symmetrically and counts correctly
-    solver.analyse(A, -1.0)
+    solver = SparseSymmetricSolver()
+    solver.analyse(A, 0.0)
     solver.factorize()
-    assert solver.inertia() == (int(np.sum(np.linalg.eigvalsh(A.toarray()) < -1.0)),
-                                n - int(np.sum(np.linalg.eigvalsh(A.toarray()) < -1.0)))
+    assert solver.inertia() == (int(np.sum(ev < 0)), int(np.sum(ev > 0)))
+    np.random.seed(1)
+    lmd, x, status = partial_hevp(A, sigma=0.0, which=3, tol=1e-9, verb=-1)
+    assert status == 0
+    near = ev[np.argsort(np.abs(ev))[:3]]                # (the solver may return more than it was asked for)
+    assert len(lmd) >= 3 and all(np.min(np.abs(lmd - v)) < 1e-8 for v in near)
+    # a definite shift of the same matrix: both factorisations count alike
+    for method in ('superlu', 'ldlt'):
+        solver = SparseSymmetricSolver(method=method)
+        solver.analyse(A, -1.0)
+        solver.factorize()
+        assert solver.inertia() == (int(np.sum(ev < -1.0)), n - int(np.sum(ev < -1.0)))
 
 
 def test_device_chebyshev_preconditioner():
@@ -391,7 +403,7 @@ def test_shift_invert_moves_no_block_across_pcie(fake, golden_dir):
     A = lap3d(30, 30, 30, 1.0, 1.01, 1.02)
     out = {}
     for device in (True, False):
-        solver = SparseSymmetricSolver(device=device)
+        solver = SparseSymmetricSolver(device=device, method='ldlt' if device else 'superlu')
         solver.analyse(A, 0.0)
         solver.factorize()
         np.random.seed(1)
@@ -400,7 +412,8 @@ def test_shift_invert_moves_no_block_across_pcie(fake, golden_dir):
         out[device] = (lmd, partial_hevp.last['iterations'], fake.calls.get('block_transfer', 0) - before)
         assert status == 0 and np.allclose(lmd[:6], k['eigenvalues'], rtol=1e-10)
     assert abs(out[True][1] - 17) <= 3
-    assert out[True][2] <= 4                              # start block in, eigenvectors out: nothing per iteration
+    # the pivot order (twice) and the two arrays of D^-1 at set-up, start block in, eigenvectors out: nothing per iteration
+    assert out[True][2] <= 6
     assert out[False][2] >= 2 * out[False][1]             # the host solve: two transfers per application
 
 
