@@ -422,6 +422,42 @@ def config_legs(L):
                    'iterations': int(partial_hevp.last['iterations']), 'smallest': [float(v) for v in lmd[:3]]}
     out['config3'] = c3
     del op, X, Y, T, B_, Z_
+    # ---- config 1 (the reference's CPU-runnable case: lap3d, six eigenvalues nearest 0 by DIRECT shift-invert)
+    from raleigh_amd.algebra.hip.host_ops import SparseSymmetricSolver
+    from raleigh_amd.synthetic import lap3d_rows
+    from oracle.sparse import lap3d_eigenvalues                      # (the checker: closed-form spectrum)
+    N1 = 32
+    A1 = lap3d_rows(N1, N1, N1, 1.0, 1.01, 1.02, 0, N1 ** 3)
+    c1 = {'workload': 'lap3d %d^3 = %d rows fp64, 6 eigenvalues nearest 0, direct shift-invert: L D L^H on the host '
+                      '(multifrontal, 1x1 / 2x2 pivots), L^-1 / D^-1 / L^-H on the device' % (N1, N1 ** 3)}
+    t0 = time.perf_counter()
+    sol = SparseSymmetricSolver()
+    sol.analyse(A1, 0.0)
+    sol.factorize()
+    c1['factorize_host_seconds'] = round(time.perf_counter() - t0, 3)
+    t1 = time.perf_counter()
+    chain = sol._device_chain()
+    _lib.check(L.rlh_sync())
+    c1['device_operators_seconds'] = round(time.perf_counter() - t1, 3)
+    info = sol.factors().info
+    c1['factor_entries'] = int(info['nnz_l'])
+    c1['largest_front'] = int(info['max_front'])
+    c1['inertia'] = list(sol.inertia())
+    B1, X1 = Vectors(N1 ** 3, 8), Vectors(N1 ** 3, 8)
+    B1.fill_random()
+    c1['apply_ms_8_vectors'] = round(timed_calls(L, lambda: sol.solve(B1, X1), 5), 3)
+    c1['levels'] = [int(v) for v in chain.levels]
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    lmd, x, status = partial_hevp(sol, which=6, tol=1e-6, verb=-1)
+    exact = lap3d_eigenvalues(N1, N1, N1, 1.0, 1.01, 1.02, 6)
+    c1['solve'] = {'seconds': round(time.perf_counter() - t0, 3),
+                   'setup_seconds': round(c1['factorize_host_seconds'] + c1['device_operators_seconds'], 3),
+                   'setup_what': 'host L D L^H factorisation + device triangular-solve set-up', 'status': int(status),
+                   'iterations': int(partial_hevp.last['iterations']),
+                   'max_rel_error_vs_closed_form': float(np.max(np.abs(np.sort(lmd)[:6] - exact) / exact))}
+    out['config1'] = c1
+    del sol, chain, B1, X1
     # ---- config 5 (one GPU: n = 126^3, complex128, m = 64)
     N, m = 126, 64
     n = N ** 3

@@ -27,15 +27,15 @@ def _saddle(rng, nk, nc):
     return scs.bmat([[K, B.T], [B, None]], format='csr')
 
 
-@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.complex128, 1e-10), (np.float32, 5e-3), (np.complex64, 5e-3)])
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.complex128, 1e-10), (np.float32, None), (np.complex64, None)])
 def test_solve_with_two_by_two_and_delayed_pivots(dtype, tol):
     from raleigh_amd.algebra.hip import Vectors
     from raleigh_amd.algebra.hip.host_ops import SparseSymmetricSolver
     rng = np.random.default_rng(17)
     cplx = np.dtype(dtype).kind == 'c'
-    pairs = 2.0 * scs.kron(scs.identity(1250), np.array([[0.0, 1.0], [1.0, 0.0]]))     # zero diagonal, no zero row
-    for a, sigma in ((_saddle(rng, 3000, 700), 0.0), ((_rand_sym(rng, 2500, 0.002, cplx=cplx) + pairs).tocsr(), 0.0),
-                     (_rand_sym(rng, 1500, 0.004, cplx=cplx, shift=0.3), 0.11)):
+    pairs = 2.0 * scs.kron(scs.identity(600), np.array([[0.0, 1.0], [1.0, 0.0]]))     # zero diagonal, no zero row
+    for a, sigma in ((_saddle(rng, 1500, 350), 0.0), ((_rand_sym(rng, 1200, 0.004, cplx=cplx) + pairs).tocsr(), 0.0),
+                     (_rand_sym(rng, 800, 0.008, cplx=cplx, shift=0.3), 0.11)):
         n = a.shape[0]
         solver = SparseSymmetricSolver(dtype=dtype)
         solver.analyse(a, sigma)
@@ -47,10 +47,18 @@ def test_solve_with_two_by_two_and_delayed_pivots(dtype, tol):
         b.fill_random()
         solver.solve(b, x)
         wide = np.complex128 if cplx else np.float64
-        ref = sla.spsolve((a - sigma * scs.identity(n)).tocsc().astype(wide), b.data().T.astype(wide))
-        assert np.max(np.abs(x.data().T - ref)) <= tol * np.max(np.abs(ref))
+        shifted = (a - sigma * scs.identity(n)).tocsc().astype(wide)
+        bh = b.data().T.astype(wide)
+        ref = sla.spsolve(shifted, bh)
+
+        def good(xh):
+            if tol is not None:
+                return np.max(np.abs(xh - ref)) <= tol * np.max(np.abs(ref))
+            # single precision factors (threshold pivoting allows growth): judged by the backward error
+            return np.max(np.abs(shifted @ xh - bh)) <= 2e-4 * (np.max(np.abs(bh)) + abs(shifted).sum(axis=1).max() * np.max(np.abs(xh)))
+        assert good(x.data().T.astype(wide))
         solver.solve(b, b)                                                # in place
-        assert np.max(np.abs(b.data().T - ref)) <= tol * np.max(np.abs(ref))
+        assert good(b.data().T.astype(wide))
         if sigma == 0.0:
             assert info['two_by_two'] + info['delayed'] > 0               # zero diagonal entries: no 1 x 1 pivot there
 
