@@ -92,6 +92,7 @@ struct rlh_csr {
   int32_t *stk_sched_part[2];
   int64_t stk_sched_part_len[2];
   int stk_grid_part[2];
+  int stk_self;            // slot 7 of every row of the stacks holds the position of the row's own column (fused Chebyshev step)
   int stk_aligned;         // every staging group of the stacks starts on a multiple of 8 columns
   int stk_overhang;        // columns (< 8) the last staging group reaches past n_cols: the callers' leading dimensions must cover them
   double stk_staged;       // staged elements per row and vector (diagnostic; the unstacked layout's: well_staged)

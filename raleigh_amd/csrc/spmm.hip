@@ -727,7 +727,13 @@ __device__ __forceinline__ void stk_store(c64 *p, c64 v) {
 
 // (DBG: timing-only builds for tools/stack_bench.py -- 1: no DMA, 2: no LDS reads / arithmetic, 4: no stores: wrong
 // results; 8: plain instead of non-temporal stores)
-template <typename T, int R, int LD, int DBG = 0>
+// CHEB (16-byte elements): the fused Chebyshev step  P = cy y + cp P + cb (B - A y)  on the same ring -- X is y (staged),
+// Y is P (read and written in place), y[row] comes out of the staged image (slot 7 of every row holds its own column's
+// position: stk_self).  P and B are ordinary loads, and ordinary loads and LDS-DMAs do not retire in order with each other
+// (see the waits below), so this variant never counts: every wait is for everything.  With the two slots of a 16-byte ring
+// that costs nothing in depth -- the DMA of vector j + 1 and the operands of vector j are in flight together while the
+// products of vector j are formed, one wait, then the update and its stores.
+template <typename T, int R, int LD, int DBG = 0, bool CHEB = false>
 __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__restrict__ meta,
                                                               const int32_t *__restrict__ member,
                                                               const int32_t *__restrict__ gsrc,
@@ -737,9 +743,10 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
                                                               const int32_t *__restrict__ sched, int64_t sched_len,
                                                               const T *__restrict__ X, int64_t ldx, int64_t n_own,
                                                               const T *__restrict__ H, int64_t ldh,
-                                                              T *__restrict__ Y, int64_t ldy, int m) {
+                                                              T *__restrict__ Y, int64_t ldy, int m, ChebArgs<T> cheb) {
   constexpr int WMAX = 8;
   constexpr int NB = StkRing<T>::NB, D = NB - 1;   // D vectors ahead
+  static_assert(!CHEB || NB == 2, "the fused step drains the ring every vector: two slots only");
   constexpr int SLOT = StkRing<T>::SLOT;
   constexpr int EPL = 16 / (int)sizeof(T);         // elements per 16-byte piece
   constexpr int LPG = 64 / EPL;
@@ -837,6 +844,52 @@ __global__ __launch_bounds__(1024) void well_stack_dma_kernel(const WellMeta *__
     };
     // every wave is done with the previous stack's slots (its last vectors were read after the last barrier)
     __builtin_amdgcn_s_barrier();
+    if constexpr (CHEB) {
+      issue(0);
+      for (int j = 0; j < m; ++j) {
+        if (j == 0) wait_vm_outstanding(0);        // (later vectors: drained by the wait below)
+        // every wave's pieces of vector j have landed, and every wave has formed its products of vector j - 1: the
+        // other slot is free
+        __builtin_amdgcn_s_barrier();
+        if (j + 1 < m) issue(j + 1);
+        unsigned boff = (unsigned)(j & (NB - 1)) * (unsigned)SLOT;
+        asm volatile("" : "+s"(boff));
+        // one member at a time -- products, operands, wait, update: the kernel sits at the 128 registers a wave of a
+        // 1024-thread workgroup has (the entries alone are 16 per row), and a spilled operand is reloaded behind a wait of
+        // its own.  Slot 7 is the row's own column with value 0: y[row], not part of the product.  The first member's
+        // wait covers the ring's DMA, which has been in flight since before its products.
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (r >= nmem) break;
+          T acc = zero_of(T{});
+#pragma unroll
+          for (int t = 0; t < WMAX - 2; t += 2) {
+            unsigned w = ixb[r][t / 2];
+            asm volatile("" : "+v"(w));
+            fma_acc(acc, v[r][t], *reinterpret_cast<const T *>(ldsb + ((w & 0xffffu) * (unsigned)sizeof(T) + boff)));
+            fma_acc(acc, v[r][t + 1], *reinterpret_cast<const T *>(ldsb + ((w >> 16) * (unsigned)sizeof(T) + boff)));
+          }
+          unsigned w = ixb[r][WMAX / 2 - 1];
+          asm volatile("" : "+v"(w));
+          fma_acc(acc, v[r][WMAX - 2], *reinterpret_cast<const T *>(ldsb + ((w & 0xffffu) * (unsigned)sizeof(T) + boff)));
+          const T yv = *reinterpret_cast<const T *>(ldsb + ((w >> 16) * (unsigned)sizeof(T) + boff));
+          T out = sub_of(scale_of(cheb.cy, yv), scale_of(cheb.cb, acc));
+          const bool live = whole || row[r] >= 0;
+          T *pp = Y + (int64_t)row[r] + (int64_t)j * ldy;
+          T pv = zero_of(T{}), bv = zero_of(T{});
+          if (live) {
+            pv = *pp;
+            bv = cheb.B[(int64_t)row[r] + (int64_t)j * cheb.ldb];
+          }
+          wait_vm_outstanding(0);
+          stk_touch(pv);
+          stk_touch(bv);
+          out = add_of(add_of(out, scale_of(cheb.cp, pv)), scale_of(cheb.cb, bv));
+          if (live) stk_store(pp, out);
+        }
+      }
+      continue;
+    }
     for (int j = 0; j < D && j < m; ++j) issue(j);
     for (int j = 0; j < m; ++j) {
       // DMAs issued after those of vector j: the later vectors in flight.  The stores of the last steps are younger too,
@@ -1299,7 +1352,7 @@ __global__ __launch_bounds__(1024) void well_stack_cheb_bf16_kernel(const WellMe
 
 template <typename T>
 static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H,
-                        int64_t ldh, T *Y, int64_t ldy, bool dma) {
+                        int64_t ldh, T *Y, int64_t ldy, bool dma, const ChebArgs<T> *cheb = nullptr) {
   Context &c = ctx();
   const int32_t *sched = part == 0 ? h->stk_sched : h->stk_sched_part[part - 1];
   const int64_t sched_len = part == 0 ? h->stk_sched_len : h->stk_sched_part_len[part - 1];
@@ -1321,10 +1374,20 @@ static int launch_stack(const rlh_csr *h, int part, int64_t m, const T *X, int64
       hipLaunchKernelGGL((well_stack_dma_kernel<T, kStkR, LD_ __VA_ARGS__>), dim3((unsigned)grid), dim3(1024),          \
                          kStkLdsBytes, c.stream, h->stk_meta, h->stk_member, h->stk_gsrc, h->stk_idx,                   \
                          pat ? (const T *)h->stk_table : (const T *)h->stk_vals, pat, pat ? h->stk_dtab : nullptr,      \
-                         h->n_rows, sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m);                           \
+                         h->n_rows, sched, sched_len, X, ldx, n_own, H, ldh, Y, ldy, (int)m,                            \
+                         cheb ? *cheb : ChebArgs<T>{});                                                                 \
     } while (0)
     const int dbg = env_int("RLH_SPMM_STACK_DBG", 0);
     RLH_REQUIRE(h->stk_gmax <= 80 * EPL, "rlh_spmm: a stack of %d staging groups", h->stk_gmax);   // (a slot holds 40 or 80 pieces)
+    if (cheb) {
+      if constexpr (sizeof(T) == 16) {
+        RLH_STK_DMA(5, , 0, true);
+        RLH_HIP(hipGetLastError());
+        return 0;
+      } else {
+        RLH_REQUIRE(false, "rlh_spmm_cheb: the stacked fused step exists for 16-byte elements only");
+      }
+    }
     if (dbg && std::is_same<T, double>::value) {
       if constexpr (std::is_same<T, double>::value) {
         switch (dbg) {
@@ -1376,7 +1439,7 @@ static int stack_split(rlh_csr *h, int64_t n_own);
 // whose 16-byte pieces must then lie on one side of the own / halo boundary.
 template <typename T>
 static int stack_dispatch(rlh_csr *h, int part, int64_t m, const T *X, int64_t ldx, int64_t n_own, const T *H, int64_t ldh,
-                          T *Y, int64_t ldy, bool *done) {
+                          T *Y, int64_t ldy, bool *done, const ChebArgs<T> *cheb = nullptr) {
   constexpr bool cplx = std::is_same<T, c32>::value || std::is_same<T, c64>::value;
   constexpr int EPL = 16 / (int)sizeof(T);
   *done = false;
@@ -1411,8 +1474,9 @@ static int stack_dispatch(rlh_csr *h, int part, int64_t m, const T *X, int64_t l
     if (part != 0)
       if (int rc = stack_split(h, n_own)) return rc;
   }
+  if (cheb && !dma) return 0;
   *done = true;
-  return launch_stack<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, dma);
+  return launch_stack<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, dma, cheb);
 }
 
 template <int DT>
@@ -1429,6 +1493,16 @@ static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ld
     bool done = false;
     const int rc = stack_dispatch<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, &done);
     if (rc || done) return rc;
+  }
+  // the fused Chebyshev step of a 16-byte operator on the same stacks (rows of at most 7 entries that store their diagonal)
+  if (cheb != nullptr && sizeof(T) == 16 && env_int("RLH_SPMM_STACK_CHEB", 1) != 0) {
+    bool done = false;
+    if (h->stk_self) {
+      const int rc = stack_dispatch<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, &done, cheb);
+      if (rc || done) return rc;
+    }
+    // (RLH_SPMM_STACK_CHEB=2: the tests' way of knowing which kernel ran)
+    RLH_REQUIRE(env_int("RLH_SPMM_STACK_CHEB", 1) < 2, "rlh_spmm_cheb: the stacked fused step does not take this operator or call");
   }
   if (h->wide_blocks > 0) {
     switch (DT) {
@@ -1895,6 +1969,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   const size_t ne = (size_t)nst * 8 * R * kWellRows;
   std::vector<uint16_t> idx(ne, 0);
   std::vector<T> vals(ne);
+  std::atomic<int> self_ok{1};
   parallel_blocks(nst, [&](int64_t sb) {
     const std::vector<Win> &ws = swins[(size_t)sb];
     fill_group_sources(ws, ngroups[(size_t)sb], 64, gsrc.data() + meta[(size_t)sb].goff);
@@ -1915,10 +1990,20 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
             memset(&vals[(size_t)ev], 0, sizeof(T));
           }
         }
+        // the LAST slot of a row with a free one carries (value 0 and) the position of the row's OWN column, where the row
+        // stores its diagonal entry: the fused Chebyshev step then finds y[row] in the staged image instead of reading the
+        // block a second time (well_stack_dma_kernel<..., CHEB>); one row without makes the handle say so
+        if (row < n) {
+          bool has_diag = false;
+          for (int64_t e = p; e < p + len && !has_diag; ++e) has_diag = indices[e] == row;
+          if (len <= 7 && has_diag) idx[(size_t)well_idx_index(eoff, 7, l)] = (uint16_t)staged_position(ws, (int32_t)row);
+          else self_ok.store(0, std::memory_order_relaxed);
+        }
       }
     }
   });
- clk.lap("stack: entries");
+  h->stk_self = self_ok.load();
+  clk.lap("stack: entries");
   h->stk_overhang = 0;
   for (int64_t g = 0; g < goff; ++g) {
     if ((int64_t)gsrc[(size_t)g] + 64 > nc8) return 0;                  // 16-byte staging needs whole groups
@@ -2191,6 +2276,7 @@ int rlh_csr_create(rlh_csr_t *out, int dtype, int64_t n_rows, int64_t n_cols, co
   h->slice_ptr = nullptr; h->cols = nullptr; h->vals = nullptr;
   h->well_blocks = 0; h->well_meta = nullptr; h->well_gsrc = nullptr; h->well_idx = nullptr; h->well_vals = nullptr;
   h->well_ratio = 0.0; h->well_sched = nullptr; h->well_sched_len = 0; h->well_grid = 0; h->well_inbounds = 0; h->well_aligned = 0;
+  h->stk_self = 0;
   h->stk_blocks = 0; h->stk_meta = nullptr; h->stk_member = nullptr; h->stk_gsrc = nullptr; h->stk_idx = nullptr;
   h->stk_split_at = -1; h->stk_sched_part[0] = h->stk_sched_part[1] = nullptr; h->stk_sched_part_len[0] = h->stk_sched_part_len[1] = 0;
   h->stk_grid_part[0] = h->stk_grid_part[1] = 0; h->stk_aligned = 0; h->stk_gmax = 0; h->stk_overhang = 0;

@@ -687,6 +687,82 @@ def test_spmm_stacked_blocks_cut_plane_by_plane(monkeypatch, key, m):
     assert np.array_equal(Y.data(), y) if key == 'd' else cases.rel(Y.data(), y) < tol
 
 
+@pytest.mark.parametrize('align', ['0', '2'])
+def test_fused_chebyshev_step_on_stacks_complex128(monkeypatch, align):
+    """The fused Chebyshev step of a complex128 operator on the stacked LDS-DMA ring (well_stack_dma_kernel<..., CHEB>: y[row]
+    out of the staged image through slot 7 of the row, p and b as ordinary loads behind waits for everything): uniform
+    stacks and stacks cut plane by plane (members shorter than 1024 rows: idle lanes), 64 and 5 vectors, against the oracle
+    and against the interleaved kernel of the same handle; y and b untouched; RLH_SPMM_STACK_CHEB=2 makes the library
+    refuse anything but the stacked kernel, so the comparison is between the two kernels for sure."""
+    from raleigh_amd import _lib
+    from raleigh_amd.algebra.hip import Vectors, SparseSymmetricMatrix
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    monkeypatch.setenv('RLH_SPMM_STACK_ALIGN', align)
+    A = _sym(lap3d(50, 50, 23, 1.0, 1.01, 1.02), 'z')
+    n = A.shape[0]
+    op = SparseSymmetricMatrix(A)
+    assert (op.layout()[3] == 36) == (align == '2')
+    up = sp.triu(A, format='csr')
+    for m in (64, 5):
+        rng = np.random.default_rng(90 + m)
+        y0, p0, b0 = (rnd((m, n), 'z', rng) for _ in range(3))
+        want = 1.3 * y0 - 0.3 * p0 - 1.7 * (b0 - ops.csr_sym_apply(up, y0))
+        y, p, b = Vectors(y0.copy()), Vectors(p0.copy()), Vectors(b0.copy())
+        monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '2')
+        op.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+        got = p.data()
+        assert cases.rel(got, want) < 1e-13
+        assert np.array_equal(y.data(), y0) and np.array_equal(b.data(), b0)
+        monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '0')
+        p.fill(p0.copy())
+        op.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+        assert cases.rel(p.data(), got) < 1e-14
+    # a row that does not store its diagonal: no own column to find in the image -- the interleaved kernel as before
+    B = sp.lil_matrix(A)
+    B[77, 77] = 0.0
+    B = sp.csr_matrix(B)
+    B.eliminate_zeros()
+    op2 = SparseSymmetricMatrix(B)
+    y, p, b = Vectors(y0.copy()), Vectors(p0.copy()), Vectors(b0.copy())
+    monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '2')
+    with pytest.raises(_lib.RlhError):
+        op2.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+    monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '1')
+    op2.cheb_step(y, p, b, 1.3, -0.3, -1.7)
+    assert cases.rel(p.data(), 1.3 * y0 - 0.3 * p0 - 1.7 * (b0 - ops.csr_sym_apply(sp.triu(B, format='csr'), y0))) < 1e-13
+
+
+def test_fused_chebyshev_step_on_stacks_repeats_at_config5_size(monkeypatch):
+    """BASELINE config 5's operator (126^3, complex128, 64 vectors, every member of a stack shorter than 1024 rows): 100 fused
+    steps from the same p, each bit for bit the first (every wait of this kernel is for everything outstanding: a race would
+    show as a difference once in thousands of stacks), the first against the interleaved kernel."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import hermitian_lap3d_rows
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.delenv('RLH_SPMM_STACK', raising=False)
+    N, m = 126, 64
+    n = N ** 3
+    op = CsrOperator(hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, 0, n))
+    y, p, b, p0 = (Vectors(n, m, data_type=np.complex128) for _ in range(4))
+    for v in (y, p0, b):
+        v.fill_random()
+    monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '2')
+    first = None
+    for it in range(100):
+        p0.copy(p)
+        op.cheb_step_ptr(m, y, p, b, 0.9, -0.2, 0.011)
+        got = p.data()
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got, first), 'fused step %d differs' % it
+    monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '0')
+    p0.copy(p)
+    op.cheb_step_ptr(m, y, p, b, 0.9, -0.2, 0.011)
+    assert cases.rel(p.data(), first) < 1e-14
+
+
 def test_plane_aligned_stacks_repeat_at_config5_size(monkeypatch):
     """The stacks of BASELINE config 5's operator (126^3, complex128: row blocks cut plane by plane, EVERY member shorter than
     1024 rows, so every wait of the LDS-DMA ring is a counted one on a stack with idle lanes): 300 products of 64 vectors, each
