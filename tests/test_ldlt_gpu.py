@@ -135,5 +135,5 @@ def test_interior_eigenvalues_of_a_saddle_point_matrix():
     assert status == 0
     want = np.r_[np.sort(ev[ev < 0])[-3:], np.sort(ev[ev > 0])[:4]]
     assert all(np.min(np.abs(lmd - v)) < 1e-8 * max(1.0, abs(v)) for v in want)
-    r = S @ x.data().T - x.data().T * lmd
+    r = S @ x - x * lmd
     assert np.max(np.linalg.norm(r, axis=0)) < 1e-6
