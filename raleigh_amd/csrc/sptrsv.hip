@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <complex>
 #include <memory>
 #include <thread>
@@ -935,6 +936,14 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
   using H = typename HostOf<DT>::H;
   const T *values = (const T *)values_;
   const int64_t n = t->n;
+  const bool verbose = env_int("RLH_SPTRSV_VERBOSE", 0) != 0;      // wall time of the phases of the set-up on stderr
+  auto clock0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "sptrsv set-up: %-28s %.3f s\n", what, std::chrono::duration<double>(now - clock0).count());
+    clock0 = now;
+  };
   std::vector<H> diag((size_t)n, H(1.0));
   int64_t nstrict = 0;
   for (int64_t i = 0; i < n; ++i) {
@@ -968,119 +977,145 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     rp.assign((size_t)n + 1, 0);
     nx.assign((size_t)n, 0);
     cols.clear(); vals.clear();
-    cols.reserve((size_t)nstrict + (size_t)n);
-    vals.reserve((size_t)nstrict + (size_t)n);
     const double fmax = 0.3;
-    std::vector<int64_t> seen((size_t)n, -1), member((size_t)n, -1);
-    std::vector<int32_t> local((size_t)n, 0);
-    std::vector<H> wv((size_t)n, H(0.0));
-    std::vector<int32_t> touched;
-    std::vector<H> D, W;
-    // rows are produced in solve order; their entries are parked per block and copied out by row afterwards
-    std::vector<std::vector<int32_t>> bc((size_t)B);
-    std::vector<std::vector<T>> bv((size_t)B);
-    std::vector<int64_t> row_start((size_t)n, 0), row_len((size_t)n, 0);
-    std::vector<int32_t> pc;                       // parked columns / values of all rows, in production order
-    std::vector<T> pv;
-    pc.reserve((size_t)nstrict + (size_t)n);
-    pv.reserve((size_t)nstrict + (size_t)n);
-    int64_t s = 0, nb = 0;
-    while (s < n) {
-      // grow the chain
-      const int64_t r0 = row_at(s);
-      member[(size_t)r0] = nb; local[(size_t)r0] = 0;
-      int64_t acc = 0, old_total = 0, new_total = 0;
-      for (int64_t e = indptr[r0]; e < indptr[r0 + 1]; ++e) {
-        const int32_t j = indices[e];
-        if (j == r0) continue;
-        if (seen[(size_t)j] != nb) { seen[(size_t)j] = nb; ++acc; }
-        ++old_total;
-      }
-      new_total = acc + 1;
-      int k = 1;
-      while (k < B && s + k < n) {
-        const int64_t rj = row_at(s + k), rprev = row_at(s + k - 1);
-        bool chained = false;
-        int64_t fresh = 0, cnt = 0;
-        for (int64_t e = indptr[rj]; e < indptr[rj + 1]; ++e) {
+    // ---- the chains, in solve order (serial: a chain starts where the one before ends)
+    std::vector<int64_t> chain_s;
+    std::vector<int32_t> chain_k;
+    {
+      std::vector<int64_t> seen((size_t)n, -1), member((size_t)n, -1);
+      int64_t s = 0, nb = 0;
+      while (s < n) {
+        const int64_t r0 = row_at(s);
+        member[(size_t)r0] = nb;
+        int64_t acc = 0, old_total = 0, new_total = 0;
+        for (int64_t e = indptr[r0]; e < indptr[r0 + 1]; ++e) {
           const int32_t j = indices[e];
-          if (j == rj) continue;
-          ++cnt;
-          if (j == rprev) chained = true;
-          if (member[(size_t)j] != nb && seen[(size_t)j] != nb) ++fresh;
+          if (j == r0) continue;
+          if (seen[(size_t)j] != nb) { seen[(size_t)j] = nb; ++acc; }
+          ++old_total;
         }
-        if (!chained) break;
-        const int64_t old2 = old_total + cnt, new2 = new_total + acc + fresh + (k + 1);
-        if ((double)new2 > (1.0 + fmax) * (double)old2 + 8.0) break;
-        for (int64_t e = indptr[rj]; e < indptr[rj + 1]; ++e) {
-          const int32_t j = indices[e];
-          if (j != rj && member[(size_t)j] != nb) seen[(size_t)j] = nb;
-        }
-        member[(size_t)rj] = nb; local[(size_t)rj] = k;
-        acc += fresh; old_total = old2; new_total = new2;
-        ++k;
-      }
-      // D (k x k, solve order) and W = D^-1
-      D.assign((size_t)k * k, H(0.0));
-      W.assign((size_t)k * k, H(0.0));
-      for (int i = 0; i < k; ++i) {
-        const int64_t ri = row_at(s + i);
-        D[(size_t)i * k + i] = diag[(size_t)ri];
-        for (int64_t e = indptr[ri]; e < indptr[ri + 1]; ++e) {
-          const int32_t j = indices[e];
-          if (j != ri && member[(size_t)j] == nb) D[(size_t)i * k + local[(size_t)j]] = D[(size_t)i * k + local[(size_t)j]] + to_h(values[e]);
-        }
-      }
-      for (int c = 0; c < k; ++c)                              // column c of the inverse by forward substitution
-        for (int i = c; i < k; ++i) {
-          H v = (i == c) ? H(1.0) : H(0.0);
-          for (int l = c; l < i; ++l) v -= D[(size_t)i * k + l] * W[(size_t)l * k + c];
-          W[(size_t)i * k + c] = v / D[(size_t)i * k + i];
-        }
-      // rows of W (D^-1) times the off-block parts
-      for (int i = 0; i < k; ++i) {
-        const int64_t ri = row_at(s + i);
-        touched.clear();
-        for (int l = 0; l <= i; ++l) {
-          const H w = W[(size_t)i * k + l];
-          if (w == H(0.0)) continue;
-          const int64_t rl = row_at(s + l);
-          for (int64_t e = indptr[rl]; e < indptr[rl + 1]; ++e) {
+        new_total = acc + 1;
+        int k = 1;
+        while (k < B && s + k < n) {
+          const int64_t rj = row_at(s + k), rprev = row_at(s + k - 1);
+          bool chained = false;
+          int64_t fresh = 0, cnt = 0;
+          for (int64_t e = indptr[rj]; e < indptr[rj + 1]; ++e) {
             const int32_t j = indices[e];
-            if (j == rl || member[(size_t)j] == nb) continue;
-            if (seen[(size_t)j] != -2 - ri) { seen[(size_t)j] = -2 - ri; wv[(size_t)j] = H(0.0); touched.push_back(j); }
-            wv[(size_t)j] += w * to_h(values[e]);
+            if (j == rj) continue;
+            ++cnt;
+            if (j == rprev) chained = true;
+            if (member[(size_t)j] != nb && seen[(size_t)j] != nb) ++fresh;
+          }
+          if (!chained) break;
+          const int64_t old2 = old_total + cnt, new2 = new_total + acc + fresh + (k + 1);
+          if ((double)new2 > (1.0 + fmax) * (double)old2 + 8.0) break;
+          for (int64_t e = indptr[rj]; e < indptr[rj + 1]; ++e) {
+            const int32_t j = indices[e];
+            if (j != rj && member[(size_t)j] != nb) seen[(size_t)j] = nb;
+          }
+          member[(size_t)rj] = nb;
+          acc += fresh; old_total = old2; new_total = new2;
+          ++k;
+        }
+        chain_s.push_back(s);
+        chain_k.push_back(k);
+        s += k;
+        ++nb;
+      }
+      t->nblocks = nb;
+    }
+    // ---- the rows of every chain: W = D^-1 times the off-block parts.  The chains are independent of each other:
+    // dealt to the host threads (every thread with marks of its own, as many threads as a gigabyte of marks allows);
+    // a thread parks the rows it produces in a buffer of its own, the rows are copied out in row order afterwards --
+    // the result does not depend on the thread count.
+    const int64_t nchains = (int64_t)chain_s.size();
+    const int want = nstrict > 2000000 ? (int)std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)(1e9 / (24.0 * (double)(n + 1))))) : 1;
+    std::vector<std::vector<int32_t>> pcs((size_t)std::max(want, 1));
+    std::vector<std::vector<T>> pvs((size_t)std::max(want, 1));
+    std::vector<int64_t> row_start((size_t)n, 0), row_len((size_t)n, 0);
+    std::vector<int8_t> row_buf((size_t)n, 0);
+    std::atomic<int64_t> next_chain(0);
+    host_parallel(want, [&](int tid, int) {
+      std::vector<int64_t> mark((size_t)n, -1);
+      std::vector<H> wv((size_t)n, H(0.0));
+      std::vector<int32_t> touched;
+      std::vector<H> D, W;
+      std::vector<int32_t> &pc = pcs[(size_t)tid];
+      std::vector<T> &pv = pvs[(size_t)tid];
+      for (;;) {
+        const int64_t c0 = next_chain.fetch_add(256);
+        if (c0 >= nchains) break;
+        for (int64_t c = c0; c < std::min(nchains, c0 + 256); ++c) {
+          const int64_t s = chain_s[(size_t)c];
+          const int k = chain_k[(size_t)c];
+          auto local_of = [&](int32_t j) -> int64_t {        // index of row j in this chain, or -1
+            const int64_t q = (t->lower ? (int64_t)j : n - 1 - (int64_t)j) - s;
+            return (q >= 0 && q < k) ? q : -1;
+          };
+          // D (k x k, solve order) and W = D^-1
+          D.assign((size_t)k * k, H(0.0));
+          W.assign((size_t)k * k, H(0.0));
+          for (int i = 0; i < k; ++i) {
+            const int64_t ri = row_at(s + i);
+            D[(size_t)i * k + i] = diag[(size_t)ri];
+            for (int64_t e = indptr[ri]; e < indptr[ri + 1]; ++e) {
+              const int32_t j = indices[e];
+              const int64_t q = j != ri ? local_of(j) : -1;
+              if (q >= 0) D[(size_t)i * k + q] = D[(size_t)i * k + q] + to_h(values[e]);
+            }
+          }
+          for (int cc = 0; cc < k; ++cc)                          // column cc of the inverse by forward substitution
+            for (int i = cc; i < k; ++i) {
+              H v = (i == cc) ? H(1.0) : H(0.0);
+              for (int l = cc; l < i; ++l) v -= D[(size_t)i * k + l] * W[(size_t)l * k + cc];
+              W[(size_t)i * k + cc] = v / D[(size_t)i * k + i];
+            }
+          for (int i = 0; i < k; ++i) {
+            const int64_t ri = row_at(s + i);
+            touched.clear();
+            for (int l = 0; l <= i; ++l) {
+              const H w = W[(size_t)i * k + l];
+              if (w == H(0.0)) continue;
+              const int64_t rl = row_at(s + l);
+              for (int64_t e = indptr[rl]; e < indptr[rl + 1]; ++e) {
+                const int32_t j = indices[e];
+                if (j == rl || local_of(j) >= 0) continue;
+                if (mark[(size_t)j] != ri) { mark[(size_t)j] = ri; wv[(size_t)j] = H(0.0); touched.push_back(j); }
+                wv[(size_t)j] += w * to_h(values[e]);
+              }
+            }
+            row_buf[(size_t)ri] = (int8_t)tid;
+            row_start[(size_t)ri] = (int64_t)pc.size();
+            for (int32_t j : touched) {
+              T v;
+              from_h(wv[(size_t)j], v);
+              pc.push_back(j); pv.push_back(v);
+            }
+            nx[(size_t)ri] = (int32_t)touched.size();
+            for (int l = 0; l <= i; ++l) {
+              const H w = W[(size_t)i * k + l];
+              if (w == H(0.0) && l != i) continue;
+              T v;
+              from_h(-w, v);
+              pc.push_back((int32_t)row_at(s + l)); pv.push_back(v);
+            }
+            row_len[(size_t)ri] = (int64_t)pc.size() - row_start[(size_t)ri];
           }
         }
-        row_start[(size_t)ri] = (int64_t)pc.size();
-        for (int32_t j : touched) {
-          T v;
-          from_h(wv[(size_t)j], v);
-          pc.push_back(j); pv.push_back(v);
-        }
-        nx[(size_t)ri] = (int32_t)touched.size();
-        for (int l = 0; l <= i; ++l) {
-          const H w = W[(size_t)i * k + l];
-          if (w == H(0.0) && l != i) continue;
-          T v;
-          from_h(-w, v);
-          pc.push_back((int32_t)row_at(s + l)); pv.push_back(v);
-        }
-        row_len[(size_t)ri] = (int64_t)pc.size() - row_start[(size_t)ri];
-        // (the marks of this row must not be mistaken for the chain's: re-mark what the chain has seen)
-        for (int32_t j : touched) seen[(size_t)j] = nb;
       }
-      s += k;
-      ++nb;
-    }
-    t->nblocks = nb;
+    });
     for (int64_t i = 0; i < n; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + row_len[(size_t)i];
-    cols.resize(pc.size());
-    vals.resize(pv.size());
-    for (int64_t i = 0; i < n; ++i) {
-      std::copy(pc.begin() + row_start[(size_t)i], pc.begin() + row_start[(size_t)i] + row_len[(size_t)i], cols.begin() + rp[(size_t)i]);
-      std::copy(pv.begin() + row_start[(size_t)i], pv.begin() + row_start[(size_t)i] + row_len[(size_t)i], vals.begin() + rp[(size_t)i]);
-    }
+    cols.resize((size_t)rp[(size_t)n]);
+    vals.resize((size_t)rp[(size_t)n]);
+    host_parallel(want, [&](int tid, int nt) {
+      for (int64_t i = n * tid / nt; i < n * (tid + 1) / nt; ++i) {
+        const std::vector<int32_t> &pc = pcs[(size_t)row_buf[(size_t)i]];
+        const std::vector<T> &pv = pvs[(size_t)row_buf[(size_t)i]];
+        std::copy(pc.begin() + row_start[(size_t)i], pc.begin() + row_start[(size_t)i] + row_len[(size_t)i], cols.begin() + rp[(size_t)i]);
+        std::copy(pv.begin() + row_start[(size_t)i], pv.begin() + row_start[(size_t)i] + row_len[(size_t)i], vals.begin() + rp[(size_t)i]);
+      }
+    });
     // dependency levels of the transformed rows (x entries only)
     nlev = 0;
     for (int64_t s = 0; s < n; ++s) {
@@ -1105,9 +1140,11 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
       plain = std::max(plain, l + 1);
     }
     t->levels_plain = plain;
+    lap("checks, plain levels");
     const int B = block_limit();
     transform(B);
-    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.9 * (double)plain) transform(1);
+    lap("block transform");
+    if (B > 1 && !getenv("RLH_SPTRSV_BLOCK") && (double)nlev > 0.9 * (double)plain) { transform(1); lap("transform undone"); }
   }
   t->lev_off.assign((size_t)nlev + 1, 0);
   for (int64_t i = 0; i < n; ++i) t->lev_off[(size_t)level[(size_t)i] + 1]++;
@@ -1128,28 +1165,42 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
     std::vector<T> vals2(vals.size());
     t->dep_pos_h.assign(cols.size(), -1);
     t->nx_h.resize((size_t)n);
-    std::vector<std::pair<int32_t, int64_t>> key;
-    int64_t w = 0;
     for (int64_t p = 0; p < n; ++p) {
       const int64_t r = order[(size_t)p];
-      const int64_t e0 = rp[(size_t)r], ex = e0 + nx[(size_t)r], e1 = rp[(size_t)r + 1];
-      key.clear();
-      for (int64_t e = e0; e < ex; ++e) key.push_back({pos_of[(size_t)cols[(size_t)e]], e});
-      std::sort(key.begin(), key.end());
-      for (auto &ke : key) {
-        cols2[(size_t)w] = ke.first;
-        vals2[(size_t)w] = vals[(size_t)ke.second];
-        t->dep_pos_h[(size_t)w] = ke.first;
-        ++w;
-      }
-      for (int64_t e = ex; e < e1; ++e, ++w) { cols2[(size_t)w] = cols[(size_t)e]; vals2[(size_t)w] = vals[(size_t)e]; }
-      rp2[(size_t)p + 1] = w;
+      rp2[(size_t)p + 1] = rp2[(size_t)p] + (rp[(size_t)r + 1] - rp[(size_t)r]);
       t->nx_h[(size_t)p] = nx[(size_t)r];
     }
+    // (the positions are independent of each other: dealt to the host threads in chunks; a direct factor has hundreds of
+    // entries per row to sort)
+    std::atomic<int64_t> next_chunk(0);
+    const int64_t chunk = 512;
+    host_parallel(cols.size() > 2000000 ? 16 : 1, [&](int, int) {
+      std::vector<std::pair<int32_t, int64_t>> key;
+      for (;;) {
+        const int64_t p0 = next_chunk.fetch_add(chunk);
+        if (p0 >= n) break;
+        for (int64_t p = p0; p < std::min(n, p0 + chunk); ++p) {
+          const int64_t r = order[(size_t)p];
+          const int64_t e0 = rp[(size_t)r], ex = e0 + nx[(size_t)r], e1 = rp[(size_t)r + 1];
+          int64_t w = rp2[(size_t)p];
+          key.clear();
+          for (int64_t e = e0; e < ex; ++e) key.push_back({pos_of[(size_t)cols[(size_t)e]], e});
+          std::sort(key.begin(), key.end());
+          for (auto &ke : key) {
+            cols2[(size_t)w] = ke.first;
+            vals2[(size_t)w] = vals[(size_t)ke.second];
+            t->dep_pos_h[(size_t)w] = ke.first;
+            ++w;
+          }
+          for (int64_t e = ex; e < e1; ++e, ++w) { cols2[(size_t)w] = cols[(size_t)e]; vals2[(size_t)w] = vals[(size_t)e]; }
+        }
+      }
+    });
     rp.swap(rp2); cols.swap(cols2); vals.swap(vals2);
   }
   t->rowptr_h = rp;
   t->entries = (int64_t)cols.size();
+  lap("level order");
   RLH_HIP(hipMalloc((void **)&t->cols, std::max<size_t>(cols.size(), 1) * sizeof(int32_t)));
   RLH_HIP(hipMalloc((void **)&t->vals, std::max<size_t>(vals.size(), 1) * sizeof(T)));
   if (!cols.empty()) {
@@ -1159,6 +1210,7 @@ static int sptrsv_build(rlh_sptrsv *t, const int64_t *indptr, const int32_t *ind
   RLH_HIP(hipMalloc((void **)&t->pos_of, std::max<size_t>((size_t)n, 1) * sizeof(int32_t)));
   if (n > 0) RLH_HIP(hipMemcpy(t->pos_of, pos_of.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
   t->device_bytes = (int64_t)cols.size() * (4 + (int64_t)sizeof(T)) + n * 4 + n * 16;
+  lap("upload");
   return 0;
 }
 
