@@ -362,6 +362,9 @@ template <typename T> struct FrontKernel {
   int64_t k, kp;        // eliminated so far; start of the open panel
   const double *colmax; // largest entry of A in the column of every variable: what "numerically zero" is measured against
   double prel;
+  int64_t *pivots;      // pivots accepted so far (all fronts), and per variable: when it may be examined again, when it
+  int64_t *retry_at, *tried_at;   // was last examined, how often it has been refused
+  int8_t *refused;
   static constexpr int64_t nb = 64;
   double floor_of(int64_t t) const { return prel * colmax[idx[t]]; }
 
@@ -436,7 +439,16 @@ template <typename T> struct FrontKernel {
       if (k - kp >= nb - 1) close_panel();
       const int64_t end = nF;
       int npv = 0;
+      // a variable that was refused is not examined again at once (its column costs a pass over the front): only after
+      // 2, 4, ... 64 further pivots -- or when nothing else is left (second pass), so that "no pivot" is never declared
+      // on the strength of a skipped candidate
+      for (int pass = 0; pass < 2 && !npv; ++pass)
       for (int64_t t = k; t < end && !npv; ++t) {
+        const int32_t var = idx[t];
+        if (pass == 0 ? retry_at[var] > *pivots : (retry_at[var] <= *pivots || tried_at[var] == *pivots)) continue;
+        tried_at[var] = *pivots;
+        if (refused[var] < 6) ++refused[var];
+        retry_at[var] = *pivots + ((int64_t)1 << refused[var]);          // (stands if this candidate is refused)
         getcol(t, c1);
         const double dtt = mag(c1[t]);
         double gam = 0, lam = 0;
@@ -509,6 +521,7 @@ template <typename T> struct FrontKernel {
       }
       if (npv == 1) kind.push_back(0);
       else { kind.push_back(1); kind.push_back(2); }
+      *pivots += npv;
     }
     close_panel();
     st.delayed += nF - k;
@@ -738,6 +751,9 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
   std::vector<T> front, W, c1, c2;
   std::vector<int8_t> kind;
   PivotStats st;
+  int64_t pivots_done = 0;
+  std::vector<int64_t> retry_at((size_t)n, 0), tried_at((size_t)n, -1);
+  std::vector<int8_t> refused((size_t)n, 0);
   int64_t max_front = 0;
   double flops = 0;
   for (int32_t s = 0; s < nsn; ++s) {
@@ -795,6 +811,7 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
     FrontKernel<T> fk;
     fk.A = A; fk.W = W.data(); fk.c1 = c1.data(); fk.c2 = c2.data(); fk.idx = idx.data(); fk.f = f; fk.nF = nF;
     fk.colmax = colmax.data(); fk.prel = perturb_rel;
+    fk.pivots = &pivots_done; fk.retry_at = retry_at.data(); fk.tried_at = tried_at.data(); fk.refused = refused.data();
     const int64_t npiv = fk.run(ps < 0, u, kind, st);
     flops += (double)npiv * (double)f * (double)f;
     for (int64_t k = 0; k < npiv; ++k) {
