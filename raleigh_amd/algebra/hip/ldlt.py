@@ -62,7 +62,8 @@ class SymmetricFactors:
 
 
 def ldlt(matrix, perm=None, pivot_threshold=0.01, perturb=1e-13):
-    """Factorises a real symmetric / Hermitian SciPy sparse matrix (its upper triangle is read).
+    """Factorises a real symmetric / Hermitian SciPy sparse matrix (its upper triangle is read; a matrix given by its
+    lower triangle alone is mirrored first).
 
     perm: optional fill-reducing ordering (perm[new] = old), default: the library's minimum degree.
     pivot_threshold: u of the threshold partial pivoting (0 = none: positive definite matrices).
@@ -71,7 +72,10 @@ def ldlt(matrix, perm=None, pivot_threshold=0.01, perturb=1e-13):
     a = scs.csr_matrix(matrix)
     if a.shape[0] != a.shape[1]:
         raise ValueError('the matrix must be square')
-    a = scs.triu(a, format='csr')
+    up = scs.triu(a, format='csr')
+    if up.nnz <= a.shape[0] and a.nnz > up.nnz and scs.triu(a, 1).nnz == 0:
+        up = scs.csr_matrix(scs.tril(a).conj().T)      # only the LOWER triangle was given: the same matrix
+    a = up
     a.sum_duplicates()
     a.sort_indices()
     n = a.shape[0]

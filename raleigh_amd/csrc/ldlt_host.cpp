@@ -557,7 +557,9 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
     for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e) {
       const int32_t c = indices[e];
       if (c < r) continue;
-      amax = std::max(amax, mag(values[e]));
+      const double v = mag(values[e]);
+      if (!(v <= 1.79e308)) amax = v;                  // (a NaN would lose every comparison of a running maximum)
+      else if (std::isfinite(amax)) amax = std::max(amax, v);
       if (c > r) { ++ap[r + 1]; ++ap[c + 1]; }
     }
   for (int32_t i = 0; i < n; ++i) ap[i + 1] += ap[i];

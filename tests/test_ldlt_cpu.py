@@ -111,6 +111,8 @@ def test_upper_triangle_is_what_is_read_and_duplicates_are_summed():
     junk = scs.tril(scs.random(80, 80, 0.2, random_state=rng), -1)
     f1, f2 = ldlt(a), ldlt(scs.triu(a) + junk)
     assert np.array_equal(f1.order, f2.order) and np.array_equal(f1.lower.toarray(), f2.lower.toarray())
+    f4 = ldlt(scs.tril(a))                                               # the lower triangle alone: mirrored
+    assert np.array_equal(f4.order, f1.order) and np.allclose(f4.lower.toarray(), f1.lower.toarray(), atol=1e-14)
     up = scs.triu(a, format='coo')
     twice = scs.csr_matrix((np.concatenate([up.data, up.data]) * 0.5, (np.concatenate([up.row, up.row]),
                                                                         np.concatenate([up.col, up.col]))), shape=a.shape)
@@ -140,6 +142,8 @@ def test_bad_arguments():
         ldlt(a, pivot_threshold=0.9)
     with pytest.raises(_lib.RlhError):
         ldlt(scs.csr_matrix(np.array([[1.0, np.inf], [np.inf, 1.0]])))
+    with pytest.raises(_lib.RlhError):
+        ldlt(scs.csr_matrix(np.array([[1.0, 2.0, 0.0], [2.0, np.nan, 1.0], [0.0, 1.0, 3.0]])))
     with pytest.raises(ValueError):
         ldlt(scs.csr_matrix((3, 4)))
 
