@@ -4,6 +4,8 @@ against eigvalsh (what PARDISO reports in iparm[21], iparm[22]: mkl_wrap.py:354-
 delayed pivots (zero diagonal, saddle point), Hermitian ones, singular ones, and through the solver class with the
 device calls on the NumPy stand-in."""
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as scs
@@ -193,3 +195,33 @@ def test_solver_class_on_the_stand_in(fake):
     sing.analyse(g, 0.0)
     with pytest.raises(RuntimeError, match='singular'):
         sing.factorize()
+
+
+@pytest.mark.parametrize('isa', ['0', '1'])
+def test_front_update_variants_agree(isa):
+    """The rank-64 update of a front exists per instruction set (chosen once per process: baseline x86-64, AVX2 + FMA,
+    AVX-512); the other two run here in processes of their own, real and complex, against dense LAPACK like the default."""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, scipy.sparse as scs
+from raleigh_amd.algebra.hip.ldlt import ldlt
+rng = np.random.default_rng(8)
+for cplx in (False, True):
+    m = scs.random(400, 400, 0.03, random_state=rng, format='csr')
+    if cplx:
+        m = m + 1j * scs.random(400, 400, 0.03, random_state=rng, format='csr')
+    a = (m + m.conj().T + 0.2 * scs.identity(400)).tocsr()
+    f = ldlt(a)
+    L = f.lower + scs.identity(400, format='csr')
+    R = L @ f.block_diagonal() @ L.conj().T - a[f.order][:, f.order]
+    assert abs(R).max() <= 1e-11 * abs(a).max(), abs(R).max()
+    ev = np.linalg.eigvalsh(a.toarray())
+    assert f.inertia() == (int((ev < 0).sum()), int((ev > 0).sum()))
+    assert f.info['max_front'] > 100
+print('ok')
+'''
+    env = dict(os.environ, RLH_LDLT_ISA=isa)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
