@@ -369,6 +369,9 @@ class ShardedSparseMatrix:
             h = getattr(comm, 'forced_halo_rows', None)
             h = (r1 - r0) // 2 if h is None else max(1, min(int(h), r1 - r0))
             own = cols < r0 + ((r1 - r0 - h) // 8) * 8
+            # (a row's own column stays an own column, as on a real shard: kernels that look the diagonal up in the
+            # staged image -- the fused Chebyshev step on the stacks -- must see what they would see there)
+            own |= cols == np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(loc.indptr))
         halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
         owner = np.searchsorted(off, halo_cols, side='right') - 1
         # local column numbering: own rows first, then the halo rows from a multiple of 8 on (the

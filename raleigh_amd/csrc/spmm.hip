@@ -1501,6 +1501,14 @@ static int spmm_impl(rlh_csr *h, int part, int64_t m, const void *X_, int64_t ld
       const int rc = stack_dispatch<T>(h, part, m, X, ldx, n_own, H, ldh, Y, ldy, &done, cheb);
       if (rc || done) return rc;
     }
+    {
+      static bool said = false;
+      if (!said && env_int("RLH_SPMM_VERBOSE", 0) != 0) {
+        said = true;
+        fprintf(stderr, "rlh_spmm_cheb: stacked fused step not used (stacks %lld, self %d, part %d, halo %d, n_own %lld, n_cols %lld, gmax %d, aligned %d)\n",
+                (long long)h->stk_blocks, h->stk_self, part, H != nullptr, (long long)n_own, (long long)h->n_cols, h->stk_gmax, h->stk_aligned);
+      }
+    }
     // (RLH_SPMM_STACK_CHEB=2: the tests' way of knowing which kernel ran)
     RLH_REQUIRE(env_int("RLH_SPMM_STACK_CHEB", 1) < 2, "rlh_spmm_cheb: the stacked fused step does not take this operator or call");
   }
@@ -1683,11 +1691,19 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
     slots += (int64_t)width[b] * kWellRows;
   }
   h->well_ratio = slots > 0 ? (double)staged / (double)slots : 0.0;
-  if (wmax > 8 || gmax > 16 * SMAX) return 0;
+  // (the limit on a block's image is the unstacked kernel's staging buffer: a complex operator never runs that kernel -- its
+  // stacks have a ring slot of their own size, checked by stack_build)
+  if (wmax > 8 || (!stack_only && gmax > 16 * SMAX)) {
+    if (clk.on) fprintf(stderr, "csr layout: well: not built (longest row %d, largest block image %d groups of 64 columns, limit %d)\n", wmax, gmax, 16 * SMAX);
+    return 0;
+  }
   // measured (profiles/r01_spmm_windowed.txt): at 0.65 staged elements per entry slot (5-point
   // stencil) the windowed kernel is 1.27x faster than the sliced one, at 1.06 (a diagonal
   // matrix) 4 % slower
-  if (!force && staged * 10 > slots * 9) return 0;
+  if (!force && staged * 10 > slots * 9) {
+    if (clk.on) fprintf(stderr, "csr layout: well: not built (%lld staged elements for %lld entry slots)\n", (long long)staged, (long long)slots);
+    return 0;
+  }
   if (stack_only) {          // the complex types: the stacks for rlh_spmm on the whole operator, the interleaved layout for the rest
     h->well_staged = (double)staged / (double)n;
     return stack_build<DT>(h, indptr, indices, values_, wins, staged);
@@ -1800,7 +1816,17 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   h->stk_blocks = 0;
   // (fewer than 4 row blocks per CU: halving the number of work units costs more than the staging saves -- lap3d 61^3,
   // 222 blocks: 12.4 us as blocks, 14.1 us as stacks)
-  if (mode == 0 || nblocks < 2 || (mode < 2 && nblocks < 4 * (int64_t)ctx().num_cu)) return 0;
+  // A complex operator that small (the row shards of BASELINE config 5: 977 / 489 / 245 blocks on 2 / 4 / 8 GPUs) still takes
+  // the LDS-DMA kernel -- its alternative is the interleaved layout at 0.6-0.7 of the rate: as pairs while every CU gets a
+  // stack (measured on one shard of 2 / 4: product 0.44 / 0.24 ms as pairs, 0.54 / 0.29 as stacks of one, 0.77 / 0.40
+  // interleaved), as stacks of ONE block below that (one of 8: 0.15 ms, 0.18 as pairs on half the CUs, 0.19 interleaved;
+  // tools/c5_shard_bench.py).  RLH_SPMM_STACK_SINGLE=0: no stacks then, as for the real types.
+  bool single = false;
+  if (mode == 0 || nblocks < 2) return 0;
+  if (mode < 2 && nblocks < 4 * (int64_t)ctx().num_cu) {
+    if (!DType<DT>::cplx || nblocks < (int64_t)ctx().num_cu / 4 || env_int("RLH_SPMM_STACK_SINGLE", 1) == 0) return 0;
+    single = 4 * nblocks < 7 * (int64_t)ctx().num_cu;
+  }
   PhaseClock clk;
   // ---- the row ranges of the blocks: uniform 1024-row blocks, paired by greedy matching on the window-overlap graph
   std::vector<int64_t> brow;
@@ -1834,6 +1860,7 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
     for (int r = 1; r < R; ++r) {
       int32_t best = -1;
       int64_t wbest = 0;
+      if (single) { members.push_back(-1); continue; }
       for (size_t k = (size_t)(sb * R); k < members.size(); ++k)          // heaviest free neighbour of the stack so far
         for (const auto &e : adj[(size_t)members[k]])
           if (owner[(size_t)e.first] < 0 && (e.second > wbest || (e.second == wbest && best >= 0 && e.first < best))) {
@@ -1954,7 +1981,10 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   }
   h->stk_staged = (double)staged / (double)(n > 0 ? n : 1);
   h->stk_gmax = gmax;
-  if (gmax > BUFG) return 0;                                            // a stack's image must fit one buffer
+  if (gmax > BUFG) {                                                     // a stack's image must fit one buffer
+    if (clk.on) fprintf(stderr, "csr layout: stack: not built (largest image %d groups of 64 columns, a buffer holds %d)\n", gmax, BUFG);
+    return 0;
+  }
   // (the complex types: the alternative is the interleaved layout, which re-stages the windows in passes of a few vectors
   // -- config 5's operator at 160^3 in complex64: 1.87 ms there, 0.86 ms here)
   if (mode < 2 && !DType<DT>::cplx && staged * 10 > staged_unstacked * 9) return 0;

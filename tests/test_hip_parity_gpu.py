@@ -763,6 +763,102 @@ def test_fused_chebyshev_step_on_stacks_repeats_at_config5_size(monkeypatch):
     assert cases.rel(p.data(), first) < 1e-14
 
 
+@pytest.mark.parametrize('rows', [(0, 30000), (17000, 49000), (40000, 64000)])
+def test_fused_chebyshev_step_on_stacks_complex128_row_shard(monkeypatch, rows):
+    """The stacked fused step on a ROW SHARD (what every rank of a multi-GPU run of BASELINE config 5 executes): own columns
+    from y, the others from a halo block; part 1 (interior rows, handed NaNs for the halo, which it must not read) + part 2
+    (boundary rows) = the full step, against NumPy; RLH_SPMM_STACK_CHEB=2 refuses any other kernel."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.setenv('RLH_SPMM_STACK', '2')
+    A = _sym(lap3d(40, 40, 40, 1.0, 1.01, 1.02), 'z')
+    n = A.shape[0]
+    r0, r1 = rows
+    loc = sp.csr_matrix(A[r0:r1])
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    nown = r1 - r0
+    n_own_pad = -(-nown // 8) * 8
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(nown)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    nh = -(-len(halo) // 8) * 8
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr), shape=(nown, n_own_pad + nh))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    rng = np.random.default_rng(5)
+    m = 64
+    y0 = rnd((m, n), 'z', rng)
+    p0, b0 = (rnd((m, nown), 'z', rng) for _ in range(2))
+
+    def block(a, rows_alloc):
+        pad = np.zeros((m, rows_alloc), dtype=np.complex128)
+        pad[:, :a.shape[1]] = a
+        return Vectors(pad)
+    y, p, b = block(y0[:, r0:r1], n_own_pad), block(p0, n_own_pad), block(b0, n_own_pad)
+    hgood = block(y0[:, halo], nh)
+    hbad = block(np.full((m, len(halo)), np.nan, dtype=np.complex128), nh)
+    monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '2')
+    op.cheb_step_ptr(m, y, p, b, 1.3, -0.3, 0.01, hbad.data_ptr(), hbad.ld(), part=1)
+    op.cheb_step_ptr(m, y, p, b, 1.3, -0.3, 0.01, hgood.data_ptr(), hgood.ld(), part=2)
+    t = (sp.csr_matrix(A[r0:r1]) @ y0.T).T
+    want = 1.3 * y0[:, r0:r1] - 0.3 * p0 + 0.01 * (b0 - t)
+    got = p.data()[:, :nown]
+    assert np.all(np.isfinite(got))
+    assert cases.rel(got, want) < 1e-13
+    # and all rows in one call, halo in place
+    p2 = block(p0, n_own_pad)
+    op.cheb_step_ptr(m, y, p2, b, 1.3, -0.3, 0.01, hgood.data_ptr(), hgood.ld(), part=0)
+    assert np.array_equal(p2.data()[:, :nown], got)
+
+
+def test_fused_chebyshev_step_on_stacks_of_a_config5_row_shard(monkeypatch):
+    """The second of eight row shards of BASELINE config 5's operator (126^3 complex128: 250 047 rows = 15.75 grid planes, one
+    halo plane on either side), built the way ShardedSparseMatrix builds it, with the library's DEFAULT choices: the stacks
+    exist, the fused step runs on them (RLH_SPMM_STACK_CHEB=2 refuses anything else) in the two parts of an overlapped
+    exchange, and equals NumPy."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import hermitian_lap3d_rows
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.delenv('RLH_SPMM_STACK', raising=False)
+    N, m = 126, 64
+    n = N ** 3
+    r0, r1 = n // 8, 2 * (n // 8)
+    loc = sp.csr_matrix(hermitian_lap3d_rows(N, N, N, 1.0, 1.01, 1.02, r0, r1))
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    nown = r1 - r0
+    n_own_pad = -(-nown // 8) * 8
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(nown)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    nh = -(-len(halo) // 8) * 8
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr), shape=(nown, n_own_pad + nh))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    assert op.stacks()[0] > 0
+    rng = np.random.default_rng(6)
+    yown, p0, b0 = (rnd((m, nown), 'z', rng) for _ in range(3))
+    yhalo = rnd((m, len(halo)), 'z', rng)
+
+    def block(a, rows_alloc):
+        pad = np.zeros((m, rows_alloc), dtype=np.complex128)
+        pad[:, :a.shape[1]] = a
+        return Vectors(pad)
+    y, p, b = block(yown, n_own_pad), block(p0, n_own_pad), block(b0, n_own_pad)
+    hgood = block(yhalo, nh)
+    hbad = block(np.full((m, len(halo)), np.nan, dtype=np.complex128), nh)
+    monkeypatch.setenv('RLH_SPMM_STACK_CHEB', '2')
+    op.cheb_step_ptr(m, y, p, b, 0.9, -0.2, 0.011, hbad.data_ptr(), hbad.ld(), part=1)
+    op.cheb_step_ptr(m, y, p, b, 0.9, -0.2, 0.011, hgood.data_ptr(), hgood.ld(), part=2)
+    ycat = np.zeros((m, L.shape[1]), dtype=np.complex128)
+    ycat[:, :nown] = yown
+    ycat[:, n_own_pad:n_own_pad + len(halo)] = yhalo
+    want = 0.9 * yown - 0.2 * p0 + 0.011 * (b0 - (L @ ycat.T).T)
+    got = p.data()[:, :nown]
+    assert np.all(np.isfinite(got)) and cases.rel(got, want) < 1e-13
+
+
 def test_plane_aligned_stacks_repeat_at_config5_size(monkeypatch):
     """The stacks of BASELINE config 5's operator (126^3, complex128: row blocks cut plane by plane, EVERY member shorter than
     1024 rows, so every wait of the LDS-DMA ring is a counted one on a stack with idle lanes): 300 products of 64 vectors, each
