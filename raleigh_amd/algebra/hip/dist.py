@@ -62,7 +62,7 @@ class Comm:
             self.device = torch.device('cpu')
         self._red = None
         self._views = {}
-        self.forced_halo_rows = None       # (forced one-rank runs: how many own rows take the halo path; None = half)
+        self.forced_halo_rows = None       # (kept for callers of earlier rounds; the forced one-rank run now cuts the shard in two)
 
     def buffer(self, nbytes):
         """A communication buffer (device memory under RCCL, host memory under gloo)."""
@@ -363,15 +363,16 @@ class ShardedSparseMatrix:
         cols = loc.indices.astype(np.int64)
         own = (cols >= r0) & (cols < r1)
         if comm.size == 1 and comm.force:
-            # one rank exchanging with itself: the last rows of the shard (half of them, or comm.forced_halo_rows:
-            # e.g. the two boundary planes a real neighbour pair would trade) are also fetched through the halo
-            # path (pack -> send to self -> receive -> halo block), so the whole exchange runs
-            h = getattr(comm, 'forced_halo_rows', None)
-            h = (r1 - r0) // 2 if h is None else max(1, min(int(h), r1 - r0))
-            own = cols < r0 + ((r1 - r0 - h) // 8) * 8
-            # (a row's own column stays an own column, as on a real shard: kernels that look the diagonal up in the
-            # staged image -- the fused Chebyshev step on the stacks -- must see what they would see there)
-            own |= cols == np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(loc.indptr))
+            # one rank exchanging with itself, as TWO VIRTUAL RANKS: the shard is cut in the middle, a column is an own
+            # column for the rows on its side of the cut and a halo column for the rows on the other side -- what the two
+            # halves would be as real shards (for a stencil: one plane of halo rows in each direction; a row's own
+            # column always an own column, every block next to the cut with one near and one far window).  The halo rows
+            # go pack -> send to self -> receive -> halo block, so the whole exchange runs.  (Earlier rounds re-routed
+            # EVERY reference to the last rows of the shard, diagonals included, which no real shard does: it hid two
+            # layout rules that only real shards trip -- DESIGN 5.)
+            cut = r0 + (((r1 - r0) // 2) // 8) * 8
+            rows_of = np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(loc.indptr))
+            own = (cols >= cut) == (rows_of >= cut)
         halo_cols = np.unique(cols[~own])                     # global ids, sorted => grouped by owner
         owner = np.searchsorted(off, halo_cols, side='right') - 1
         # local column numbering: own rows first, then the halo rows from a multiple of 8 on (the

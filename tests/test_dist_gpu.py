@@ -65,16 +65,17 @@ def test_reductions_through_rccl(comm, dt):
 
 @pytest.mark.parametrize('dt', [np.float64, np.float32])
 def test_halo_exchange_with_itself(comm, dt):
-    """Half of the own rows is fetched through the halo path (RLH_FORCE_COLLECTIVES semantics of
-    ShardedSparseMatrix with one rank): gather_rows, batch_isend_irecv to the own rank, the strided
-    copy into the halo block and the interior / boundary split of the windowed kernel."""
+    """The forced one-rank run cuts the shard into two virtual ranks (RLH_FORCE_COLLECTIVES semantics of
+    ShardedSparseMatrix with one rank): the grid plane on either side of the cut is fetched through the halo path --
+    gather_rows, batch_isend_irecv to the own rank, the strided copy into the halo block and the interior / boundary
+    split of the windowed kernel."""
     from raleigh_amd.algebra.hip.dist import ShardedVectors, ShardedSparseMatrix
     A = lap3d(40, 40, 40, 1.0, 1.01, 1.02).astype(dt)
     n = A.shape[0]
     rng = np.random.default_rng(8)
     x = rng.standard_normal((9, n)).astype(dt)
     op = ShardedSparseMatrix(A, comm)
-    assert op.halo_rows() > n // 3                        # the forced self-exchange is really there
+    assert op.halo_rows() == 2 * 40 * 40                  # the forced self-exchange is really there: one plane each way
     X, Y = ShardedVectors(x, comm=comm), ShardedVectors(n, 9, dt, comm=comm)
     op.apply(X, Y)
     ref = ops.csr_sym_apply(sp.triu(A, format='csr'), x)
