@@ -812,6 +812,56 @@ def test_fused_chebyshev_step_on_stacks_complex128_row_shard(monkeypatch, rows):
     assert np.array_equal(p2.data()[:, :nown], got)
 
 
+@pytest.mark.parametrize('key', ['d', 's'])
+def test_product_on_a_row_shard_of_the_headline_operator(monkeypatch, key):
+    """The second of eight row shards of lap3d 215^3 (1 242 304 rows, one grid plane of halo rows on either side), built the way
+    ShardedSparseMatrix builds it, with the library's default choices: the stacks exist, interior rows + boundary rows = the
+    product of the shard's rows (SciPy), the interior part never reads the halo block (handed NaNs); float32: the operator
+    takes the bfloat16 Chebyshev step."""
+    from raleigh_amd.algebra.hip import Vectors, CsrOperator
+    from raleigh_amd.synthetic import lap3d_rows
+    monkeypatch.delenv('RLH_SPMM_FORMAT', raising=False)
+    monkeypatch.delenv('RLH_SPMM_STACK', raising=False)
+    N, m = 215, 8
+    n = N ** 3
+    per = -(-(n // 8) // 64) * 64
+    r0, r1 = per, 2 * per
+    dt = DT[key]
+    loc = sp.csr_matrix(lap3d_rows(N, N, N, 1.0, 1.01, 1.02, r0, r1)).astype(dt)
+    used = np.unique(loc.indices)
+    halo = used[(used < r0) | (used >= r1)]
+    nown = r1 - r0
+    n_own_pad = -(-nown // 8) * 8
+    newcol = np.full(n, -1, dtype=np.int64)
+    newcol[r0:r1] = np.arange(nown)
+    newcol[halo] = n_own_pad + np.arange(len(halo))
+    nh = -(-len(halo) // 8) * 8
+    L = sp.csr_matrix((loc.data, newcol[loc.indices].astype(np.int32), loc.indptr), shape=(nown, n_own_pad + nh))
+    L.sort_indices()
+    op = CsrOperator(L, n_own=n_own_pad)
+    assert op.layout()[0] == 'well' and op.stacks()[0] > 0
+    if key == 's':
+        assert op.bf16_ready(nh)
+    rng = np.random.default_rng(12)
+    xown, xhalo = rnd((m, nown), key, rng), rnd((m, len(halo)), key, rng)
+
+    def block(a, rows_alloc):
+        pad = np.zeros((m, rows_alloc), dtype=dt)
+        pad[:, :a.shape[1]] = a
+        return Vectors(pad)
+    x, y = block(xown, n_own_pad), Vectors(n_own_pad, m, data_type=dt)
+    hgood, hbad = block(xhalo, nh), block(np.full((m, len(halo)), np.nan, dtype=dt), nh)
+    y.fill(np.full((m, n_own_pad), np.nan, dtype=dt))
+    op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), hbad.data_ptr(), hbad.ld(), part=1)
+    op.apply_ptr(m, x.data_ptr(), x.ld(), y.data_ptr(), y.ld(), hgood.data_ptr(), hgood.ld(), part=2)
+    xcat = np.zeros((m, L.shape[1]), dtype=dt)
+    xcat[:, :nown] = xown
+    xcat[:, n_own_pad:n_own_pad + len(halo)] = xhalo
+    want = (L.astype(np.float64) @ xcat.T.astype(np.float64)).T
+    got = y.data()[:, :nown]
+    assert np.all(np.isfinite(got)) and cases.rel(got, want) < (3e-6 if key == 's' else 1e-13)
+
+
 def test_fused_chebyshev_step_on_stacks_of_a_config5_row_shard(monkeypatch):
     """The second of eight row shards of BASELINE config 5's operator (126^3 complex128: 250 047 rows = 15.75 grid planes, one
     halo plane on either side), built the way ShardedSparseMatrix builds it, with the library's DEFAULT choices: the stacks
