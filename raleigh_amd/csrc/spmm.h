@@ -219,6 +219,17 @@ static inline int32_t staged_position(const std::vector<Win> &ws, int32_t c) {
   return ws[lo].off + (c - ws[lo].start);
 }
 
+// the same for the entries of one row in turn: columns ascend within a (canonical) row, so the window of an entry is the
+// last one's or one of the next few -- a walk from `hint` (updated) instead of a binary search per entry; a column below the
+// last one's window (an unsorted row) starts over
+static inline int32_t staged_position_walk(const std::vector<Win> &ws, int32_t c, size_t &hint) {
+  size_t w = hint;
+  if (ws[w].start > c) return staged_position(ws, c);
+  while (w + 1 < ws.size() && ws[w + 1].start <= c) ++w;
+  hint = w;
+  return ws[w].off + (c - ws[w].start);
+}
+
 // first column of every staging group of a block (surplus groups repeat the last)
 static inline void fill_group_sources(const std::vector<Win> &ws, int32_t ngroups, int gs, int32_t *gsrc) {
   int32_t filled = 0, last = 0;
@@ -226,6 +237,19 @@ static inline void fill_group_sources(const std::vector<Win> &ws, int32_t ngroup
     for (int32_t g = 0; g < (w.len + gs - 1) / gs; ++g, ++filled) gsrc[w.off / gs + g] = last = w.start + gs * g;
   for (; filled < ngroups; ++filled) gsrc[filled] = last;
 }
+
+// host buffer whose elements are NOT zeroed at allocation (std::vector would fill 0.6 GB serially before the host threads
+// overwrite every element of it; left alone, the pages are first touched by the threads that fill them)
+template <typename E> struct RawBuf {
+  std::unique_ptr<E[]> p;
+  size_t n;
+  explicit RawBuf(size_t count) : p(new E[count > 0 ? count : 1]), n(count) {}
+  E &operator[](size_t i) { return p[i]; }
+  const E &operator[](size_t i) const { return p[i]; }
+  E *data() { return p.get(); }
+  const E *data() const { return p.get(); }
+  size_t size() const { return n; }
+};
 
 // RLH_SPMM_VERBOSE=1: wall time of the phases of a layout build on stderr
 struct PhaseClock {

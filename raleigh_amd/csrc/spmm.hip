@@ -1720,9 +1720,8 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
   std::vector<int32_t> gsrc((size_t)goff);
   const int64_t epad = 0;
-  std::vector<uint16_t> idx((size_t)(eoff + epad) * kWellRows, 0);
-  std::vector<T> vals((size_t)(eoff + epad) * kWellRows);
-  memset(vals.data() + (size_t)eoff * kWellRows, 0, (size_t)epad * kWellRows * sizeof(T));
+  RawBuf<uint16_t> idx((size_t)(eoff + epad) * kWellRows);      // (every slot of every block is written below)
+  RawBuf<T> vals((size_t)(eoff + epad) * kWellRows);
   parallel_blocks(nblocks, [&](int64_t b) {
     const std::vector<Win> &ws = wins[b];
     fill_group_sources(ws, ngroups[b], 64, gsrc.data() + meta[b].goff);
@@ -1733,10 +1732,11 @@ static int well_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices,
       // padding slots carry value 0 and the position of the row's own first entry, so that they
       // only ever touch a column the row references (0 * Inf of a foreign column would be NaN)
       const uint16_t padpos = len > 0 ? (uint16_t)staged_position(ws, indices[p]) : 0;
+      size_t hint = 0;
       for (int32_t t = 0; t < 8; ++t) {
         const int64_t ev = well_val_index<T>(meta[b].eoff, t, l), ei = well_idx_index(meta[b].eoff, t, l);
         if (t < len) {
-          idx[ei] = (uint16_t)staged_position(ws, indices[p + t]);
+          idx[ei] = (uint16_t)staged_position_walk(ws, indices[p + t], hint);
           vals[ev] = values[p + t];
         } else {
           idx[ei] = padpos;
@@ -1999,8 +1999,8 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
   RLH_REQUIRE(goff < ((int64_t)1 << 31), "rlh_csr_create: too many staging groups");
   std::vector<int32_t> gsrc((size_t)goff);
   const size_t ne = (size_t)nst * 8 * R * kWellRows;
-  std::vector<uint16_t> idx(ne, 0);
-  std::vector<T> vals(ne);
+  RawBuf<uint16_t> idx(ne);                                     // (every slot of every stack is written below)
+  RawBuf<T> vals(ne);
   std::atomic<int> self_ok{1};
   parallel_blocks(nst, [&](int64_t sb) {
     const std::vector<Win> &ws = swins[(size_t)sb];
@@ -2012,10 +2012,11 @@ static int stack_build(rlh_csr *h, const int64_t *indptr, const int32_t *indices
         const int64_t row = mb >= 0 && brow[(size_t)mb] + l < brow[(size_t)mb + 1] ? brow[(size_t)mb] + l : n;
         const int64_t p = row < n ? indptr[row] : 0, len = row < n ? indptr[row + 1] - p : 0;
         const uint16_t padpos = len > 0 ? (uint16_t)staged_position(ws, indices[p]) : 0;
+        size_t hint = 0;
         for (int32_t t = 0; t < 8; ++t) {
           const int64_t ev = well_val_index<T>(eoff, t, l), ei = well_idx_index(eoff, t, l);
           if (t < len) {
-            idx[(size_t)ei] = (uint16_t)staged_position(ws, indices[p + t]);
+            idx[(size_t)ei] = (uint16_t)staged_position_walk(ws, indices[p + t], hint);
             vals[(size_t)ev] = values[p + t];
           } else {
             idx[(size_t)ei] = padpos;
