@@ -318,6 +318,9 @@ int rlh_ldlt_factor(rlh_ldlt_t *f, int dtype, int64_t n, const int64_t *indptr,
 int rlh_ldlt_info(rlh_ldlt_t f, int64_t *info);
 int rlh_ldlt_get(rlh_ldlt_t f, int64_t *indptr, int32_t *indices, void *values, void *diag,
                  void *subdiag, int8_t *block, int64_t *order);
+/* L^H (strictly upper, unit diagonal implied, entries conjugated, columns ascending) as CSR in pivot order: the operator
+ * of the backward solve (PARDISO phase 333), which the factorisation holds anyway (it produces L by columns). */
+int rlh_ldlt_get_transposed(rlh_ldlt_t f, int64_t *indptr, int32_t *indices, void *values);
 int rlh_ldlt_destroy(rlh_ldlt_t f);
 /* X <- D^-1 X for the block diagonal D of such a factorisation, on a column-major n x m block in
  * DEVICE memory (PARDISO phase 332): d_coef holds two entries per row (DEVICE, the block's dtype):

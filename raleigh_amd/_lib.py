@@ -88,6 +88,7 @@ SIGNATURES = {
     'rlh_ldlt_factor': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, _p, ctypes.c_double, ctypes.c_double],
     'rlh_ldlt_info': [_p, _p],
     'rlh_ldlt_get': [_p, _p, _p, _p, _p, _p, _p, _p],
+    'rlh_ldlt_get_transposed': [_p, _p, _p, _p],
     'rlh_ldlt_destroy': [_p],
     'rlh_bdiag_solve': [_int, _i64, _p, _p, _i64, _p, _i64],
     'rlh_sptrsv_create': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, _int, _int],

@@ -20,8 +20,15 @@ class SymmetricFactors:
     """L (strictly lower CSR, unit diagonal implied, pivot order), the block diagonal D (diag, subdiag, block) and the
     pivot order of one factorisation; `info` as rlh_ldlt_info reports it."""
 
-    def __init__(self, lower, diag, subdiag, block, order, info):
+    def __init__(self, lower, diag, subdiag, block, order, info, upper=None):
         self.lower, self.diag, self.subdiag, self.block, self.order, self.info = lower, diag, subdiag, block, order, info
+        self.upper = upper                  # L^H as the library hands it out (None: transposed here when needed)
+
+    def lower_transposed(self):
+        """L^H (strictly upper CSR): the operator of the backward solve."""
+        if self.upper is None:
+            self.upper = self.lower.conj().T.tocsr()
+        return self.upper
 
     def inertia(self):
         """(negative, positive) eigenvalue counts of A, from D (Sylvester's law)."""
@@ -100,8 +107,10 @@ def ldlt(matrix, perm=None, pivot_threshold=0.01, perturb=1e-13):
         info = dict(zip(INFO, (int(v) for v in raw)))
         nnz = info['nnz_l']
         ip = np.zeros(n + 1, dtype=np.int64)
-        ix = np.zeros(max(nnz, 1), dtype=np.int32)
-        va = np.zeros(max(nnz, 1), dtype=dt)
+        ix = np.empty(max(nnz, 1), dtype=np.int32)
+        va = np.empty(max(nnz, 1), dtype=dt)
+        up, ux, uv = np.zeros(n + 1, dtype=np.int64), np.empty(max(nnz, 1), dtype=np.int32), np.empty(max(nnz, 1), dtype=dt)
+        _lib.check(L.rlh_ldlt_get_transposed(f, _lib.host_ptr(up), _lib.host_ptr(ux), _lib.host_ptr(uv)))
         d = np.zeros(max(n, 1), dtype=dt)
         e = np.zeros(max(n, 1), dtype=dt)
         blk = np.zeros(max(n, 1), dtype=np.int8)
@@ -111,7 +120,9 @@ def ldlt(matrix, perm=None, pivot_threshold=0.01, perturb=1e-13):
     finally:
         L.rlh_ldlt_destroy(f)
     lower = scs.csr_matrix((va[:nnz], ix[:nnz], ip), shape=(n, n))
-    return SymmetricFactors(lower, d[:n], e[:n], blk[:n], order[:n], info)
+    upper = scs.csr_matrix((uv[:nnz], ux[:nnz], up), shape=(n, n))
+    lower.has_sorted_indices = upper.has_sorted_indices = True
+    return SymmetricFactors(lower, d[:n], e[:n], blk[:n], order[:n], info, upper)
 
 
 class SymmetricSolve:
@@ -129,7 +140,7 @@ class SymmetricSolve:
             return TriangularChain([(factors.lower, True, True)], self._dtype, perm_in=factors.order)
 
         def backward():
-            return TriangularChain([(factors.lower.conj().T.tocsr(), False, True)], self._dtype, perm_out=factors.order)
+            return TriangularChain([(factors.lower_transposed(), False, True)], self._dtype, perm_out=factors.order)
         _lib.lib()
         if factors.lower.nnz > 1_000_000:
             # the host side of rlh_sptrsv_create is serial per operator and the two are independent (ctypes releases the GIL)

@@ -39,6 +39,9 @@ struct rlh_ldlt {
   std::vector<char> lval;
   std::vector<char> d, e;           // D: diagonal, and below-diagonal entry of a 2 x 2 block at its first row (else 0)
   std::vector<int8_t> blk;          // 0: 1 x 1 pivot, 1 / 2: first / second row of a 2 x 2 pivot
+  std::vector<int64_t> uptr;        // the same entries by COLUMNS of L = rows of L^H (conjugated), indices ascending
+  std::vector<int32_t> uidx;
+  std::vector<char> uval;
   std::vector<int64_t> order;       // order[k] = row of A eliminated k-th
   int64_t info[RLH_LDLT_INFO];
 };
@@ -855,19 +858,78 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
   for (int32_t k = 0; k < n; ++k) pos[seq[k]] = k;
   const int64_t nnz = (int64_t)lrow.size();
   std::vector<int64_t> &lptr = out->lptr;
-  for (int64_t e = 0; e < nnz; ++e) ++lptr[pos[lrow[e]] + 1];
-  for (int32_t i = 0; i < n; ++i) lptr[i + 1] += lptr[i];
   out->lidx.resize((size_t)nnz);
   out->lval.resize((size_t)nnz * sizeof(T));
   T *ov = reinterpret_cast<T *>(out->lval.data());
   {
-    std::vector<int64_t> fill(lptr.begin(), lptr.end() - 1);
-    for (int32_t k = 0; k < n; ++k)
-      for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
-        const int64_t q = fill[pos[lrow[e]]]++;
-        out->lidx[q] = k;
-        ov[q] = lval[e];
+    // columns -> rows on the host threads: thread t owns a range of pivot columns (equal shares of the entries), counts
+    // its entries per row, the offsets of a row are the prefix over the threads in order -- every row's entries come out in
+    // ascending column order whatever the thread count (as many threads as 256 MB of counters allow)
+    int nt = nnz > 4000000 ? (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16, host_threads()), ((int64_t)64 << 20) / ((int64_t)n + 1))) : 1;
+    std::vector<int32_t> cut((size_t)nt + 1, n);
+    cut[0] = 0;
+    for (int t = 1; t < nt; ++t)
+      cut[t] = (int32_t)(std::lower_bound(colptr.begin(), colptr.end(), nnz * t / nt) - colptr.begin());
+    for (int t = 1; t <= nt; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    cut[nt] = n;
+    std::vector<std::vector<int32_t>> cnt((size_t)nt);
+    host_parallel(nt, [&](int t, int threads) {
+      for (int q = t; q < nt; q += threads) {
+        cnt[q].assign((size_t)n, 0);
+        for (int64_t e = colptr[cut[q]]; e < colptr[cut[q + 1]]; ++e) ++cnt[q][pos[lrow[e]]];
       }
+    });
+    for (int32_t i = 0; i < n; ++i) {
+      int64_t tot = 0;
+      for (int t = 0; t < nt; ++t) tot += cnt[t][i];
+      lptr[i + 1] = lptr[i] + tot;
+    }
+    host_parallel(nt, [&](int t, int threads) {
+      for (int q = t; q < nt; q += threads) {
+        std::vector<int64_t> fill((size_t)n);
+        for (int32_t i = 0; i < n; ++i) {
+          int64_t off = lptr[i];
+          for (int u = 0; u < q; ++u) off += cnt[u][i];
+          fill[i] = off;
+        }
+        for (int32_t k = cut[q]; k < cut[q + 1]; ++k)
+          for (int64_t e = colptr[k]; e < colptr[k + 1]; ++e) {
+            const int64_t w = fill[pos[lrow[e]]]++;
+            out->lidx[w] = k;
+            ov[w] = lval[e];
+          }
+      }
+    });
+  }
+  {
+    // L^H by rows = L by columns, which is how the factorisation produced it: positions instead of variables, conjugated,
+    // every row sorted (within a front the pivot order is not the variables' order)
+    out->uptr.assign(colptr.begin(), colptr.end());
+    out->uidx.resize((size_t)nnz);
+    out->uval.resize((size_t)nnz * sizeof(T));
+    T *uv = reinterpret_cast<T *>(out->uval.data());
+    std::atomic<int32_t> next_col(0);
+    host_parallel(nnz > 4000000 ? 16 : 1, [&](int, int) {
+      std::vector<std::pair<int32_t, T>> row;
+      for (;;) {
+        const int32_t k0 = next_col.fetch_add(256);
+        if (k0 >= n) break;
+        for (int32_t k = k0; k < std::min(n, k0 + 256); ++k) {
+          const int64_t e0 = colptr[k], e1 = colptr[k + 1];
+          bool sorted = true;
+          for (int64_t e = e0; e < e1; ++e) {
+            out->uidx[(size_t)e] = pos[lrow[e]];
+            uv[e] = cj(lval[e]);
+            sorted = sorted && (e == e0 || out->uidx[(size_t)e - 1] < out->uidx[(size_t)e]);
+          }
+          if (sorted) continue;
+          row.clear();
+          for (int64_t e = e0; e < e1; ++e) row.emplace_back(out->uidx[(size_t)e], uv[e]);
+          std::sort(row.begin(), row.end(), [](const std::pair<int32_t, T> &a, const std::pair<int32_t, T> &b) { return a.first < b.first; });
+          for (int64_t e = e0; e < e1; ++e) { out->uidx[(size_t)e] = row[(size_t)(e - e0)].first; uv[e] = row[(size_t)(e - e0)].second; }
+        }
+      }
+    });
   }
   memcpy(out->d.data(), dd.data(), (size_t)n * sizeof(T));
   memcpy(out->e.data(), de.data(), (size_t)n * sizeof(T));
@@ -937,6 +999,17 @@ int rlh_ldlt_get(rlh_ldlt_t f, int64_t *indptr, int32_t *indices, void *values, 
   if (subdiag && !f->e.empty()) memcpy(subdiag, f->e.data(), f->e.size());
   if (block && !f->blk.empty()) memcpy(block, f->blk.data(), f->blk.size());
   if (order && !f->order.empty()) memcpy(order, f->order.data(), f->order.size() * sizeof(int64_t));
+  return 0;
+}
+
+int rlh_ldlt_get_transposed(rlh_ldlt_t f, int64_t *indptr, int32_t *indices, void *values) {
+  RLH_REQUIRE(f != nullptr, "rlh_ldlt_get_transposed: null handle");
+  if (indptr) {
+    if (f->uptr.empty()) memset(indptr, 0, ((size_t)f->n + 1) * sizeof(int64_t));
+    else memcpy(indptr, f->uptr.data(), f->uptr.size() * sizeof(int64_t));
+  }
+  if (indices && !f->uidx.empty()) memcpy(indices, f->uidx.data(), f->uidx.size() * sizeof(int32_t));
+  if (values && !f->uval.empty()) memcpy(values, f->uval.data(), f->uval.size());
   return 0;
 }
 

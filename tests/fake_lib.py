@@ -387,6 +387,9 @@ class FakeLib:
     def rlh_ldlt_get(self, *a):
         return self._real().rlh_ldlt_get(*a)
 
+    def rlh_ldlt_get_transposed(self, *a):
+        return self._real().rlh_ldlt_get_transposed(*a)
+
     def rlh_ldlt_destroy(self, *a):
         return self._real().rlh_ldlt_destroy(*a)
 

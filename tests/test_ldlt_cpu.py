@@ -52,6 +52,12 @@ def _check(a, **kw):
     L = low + scs.identity(n, format='csr')
     R = L @ f.block_diagonal() @ L.conj().T - a[f.order][:, f.order]
     assert abs(R).max() <= 1e-11 * max(abs(a).max(), 1e-300)
+    up = f.lower_transposed()                                             # L^H as the library hands it out: the same entries
+    assert up.has_sorted_indices and abs(up - low.conj().T).max() == 0 if n else True
+    chk = up.copy()
+    chk.has_sorted_indices = False
+    chk.sort_indices()
+    assert np.array_equal(chk.indices, up.indices)
     ev = np.linalg.eigvalsh(a.toarray())
     assert f.inertia() == (int((ev < 0).sum()), int((ev > 0).sum()))
     assert f.info['perturbed'] == 0
