@@ -4,7 +4,7 @@
 #  2. the forced-collectives bench at one rank
 #  3. this round's kernels: the config-5 inexact shift-invert solve (block MINRES), the complex128 Gram on LDS-DMA staging,
 #     the split-K dense apply in double / complex (kernel stats + MFMA-busy counters), the config-5 SpMM on plane-aligned stacks
-#  4. host set-up times, halo exchange breakdown
+#  4. host set-up times, halo exchange breakdown, the direct shift-invert (L D L^H against SuperLU), what one rank's row shard launches
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 bash $R/tools/profile_round.sh $TAG > $O/round.txt 2>&1 || { tail -5 $O/round.txt; exit 1; }
@@ -35,7 +35,11 @@ run c5_ops_stats "" python3 $R/tools/c5_ops.py 126 64
  timeout -k 10 300 python3 tools/setup_bench.py 215 0 >> $O/text.txt 2>&1
  timeout -k 10 300 python3 tools/ilut_bench.py 1 4 16 >> $O/text.txt 2>&1
  timeout -k 10 300 python3 tools/halo_bench.py 215 32 2>&1 | grep -v "NCCL\|RCCL\|version\|Hostname\|amdgpu.ids\|Librccl\|^\[W" >> $O/text.txt
- timeout -k 10 300 python3 tools/config5_solve.py 126 40 16 250 1e-8 1e-6 >> $O/text.txt 2>&1) || echo "FAILED text"
+ timeout -k 10 300 python3 tools/config5_solve.py 126 40 16 250 1e-8 1e-6 >> $O/text.txt 2>&1
+ timeout -k 10 200 python3 tools/si_bench.py 30 --m 8 >> $O/text.txt 2>&1
+ timeout -k 10 200 python3 tools/si_bench.py 40 --m 16 >> $O/text.txt 2>&1
+ timeout -k 10 200 python3 tools/si_bench.py 30 --m 64 --complex --method ldlt >> $O/text.txt 2>&1
+ for s in "8 1" "4 1" "2 0"; do set -- $s; timeout -k 10 200 python3 tools/c5_shard_bench.py $1 $2 2>&1 | grep "^shard" >> $O/text.txt; timeout -k 10 200 python3 tools/lap_shard_bench.py $1 $2 2>&1 | grep "^shard" >> $O/text.txt; done) || echo "FAILED text"
 python3 - <<PY
 import csv, glob, collections, os
 O = "$O"
@@ -60,6 +64,6 @@ for name in ("zgram_mfma", "gemm_d_mfma"):
         if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0:
             busy = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8 * 1024)
             print("  %-60s MFMA pipes busy %.1f %%  (%s)" % (k, 100 * busy, {c: int(x) for c, x in d.items()}))
-print("== text (tools/gemm_shapes.py, zgram_bench.py, c5_ops.py, stack_bench.py, setup_bench.py, ilut_bench.py, halo_bench.py, config5_solve.py)")
+print("== text (tools/gemm_shapes.py, zgram_bench.py, c5_ops.py, stack_bench.py, setup_bench.py, ilut_bench.py, halo_bench.py, config5_solve.py, si_bench.py, c5_shard_bench.py, lap_shard_bench.py)")
 print(open(O + "/text.txt").read())
 PY
