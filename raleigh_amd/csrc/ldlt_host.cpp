@@ -26,6 +26,7 @@
 #include <atomic>
 #include <chrono>
 #include <complex>
+#include <memory>
 #include <numeric>
 #include <vector>
 
@@ -354,7 +355,9 @@ template <typename T> static void trailing_update(T *A, const T *W, int64_t f, i
 // ------------------------------------------------------------------ one front
 struct PivotStats {
   int64_t two_by_two = 0, delayed = 0, perturbed = 0, negative = 0, positive = 0, forced = 0;
+  double t_update = 0, t_assemble = 0, t_pivot = 0, t_store = 0;    // (RLH_LDLT_VERBOSE: where the fronts' time goes)
 };
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <typename T> struct FrontKernel {
   T *A;                 // f x f, column-major, lower triangle live
@@ -400,8 +403,11 @@ template <typename T> struct FrontKernel {
     for (int64_t c = 0; c < k - kp; ++c) std::swap(W[p + c * f], W[q + c * f]);
     std::swap(idx[p], idx[q]);
   }
+  double *t_update = nullptr;
   void close_panel() {
+    const double t0 = t_update ? now_s() : 0.0;
     trailing_update(A, W, f, kp, k);
+    if (t_update) *t_update += now_s() - t0;
     kp = k;
   }
   void pivot1(const T *c, PivotStats &st) {
@@ -533,11 +539,37 @@ template <typename T> struct FrontKernel {
 };
 
 // ------------------------------------------------------------------ the factorisation
+// The contribution blocks live on a stack (a parent takes the blocks of its children, which are on top, and leaves its own):
+// memory for them is bumped off a list of chunks that are kept until the factorisation ends -- the C library would map and
+// unmap every block of more than 128 KB, i.e. page-fault it in again each time.
+struct BlockStack {
+  std::vector<std::unique_ptr<char[]>> chunks;
+  std::vector<size_t> cap;
+  size_t cur = 0, off = 0;
+  struct Mark { size_t cur, off; };
+  Mark mark() const { return Mark{cur, off}; }
+  void release(Mark m) { cur = m.cur; off = m.off; }
+  void *take(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    while (cur < chunks.size() && off + bytes > cap[cur]) { ++cur; off = 0; }
+    if (cur == chunks.size()) {
+      const size_t c = std::max<size_t>(bytes, (size_t)64 << 20);
+      chunks.emplace_back(new char[c]);
+      cap.push_back(c);
+      off = 0;
+    }
+    void *p = chunks[cur].get() + off;
+    off += bytes;
+    return p;
+  }
+};
+
 template <typename T> struct Contribution {
   int32_t parent;                  // supernode that takes it
   int64_t ndelayed;                // leading variables that are still to be eliminated
   std::vector<int32_t> idx;
-  std::vector<T> a;                // size x size, lower triangle live
+  T *a;                            // size x size, lower triangle live (BlockStack memory)
+  BlockStack::Mark mark;           // the stack before this block was taken
 };
 
 template <typename T>
@@ -737,6 +769,7 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
   lap("tree, counts, supernodes");
   // ---- numerical factorisation
   std::vector<Contribution<T>> stack;
+  BlockStack blocks;
   std::vector<int64_t> colptr;               // L by pivot columns: rows as variables (postordered numbering)
   std::vector<int32_t> lrow;
   std::vector<T> lval;
@@ -789,8 +822,10 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
     for (int32_t i : rows) { loc[i] = (int32_t)idx.size(); idx.push_back(i); }
     const int64_t f = (int64_t)idx.size();
     max_front = std::max(max_front, f);
-    front.assign((size_t)(f * f), T(0));
+    const double t_a = verbose ? now_s() : 0.0;
+    if ((int64_t)front.size() < f * f) front.resize((size_t)(f * f));
     T *A = front.data();
+    for (int64_t q = 0; q < f; ++q) memset((void *)(A + q * f + q), 0, (size_t)(f - q) * sizeof(T));   // (the lower triangle is what is used)
     for (int32_t j = c0; j < c1col; ++j) {
       const int64_t lj = loc[j];
       for (int64_t e = cp[j]; e < cp[j + 1]; ++e) A[loc[ci[e]] + lj * f] += cv[e];
@@ -800,7 +835,7 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
       const int64_t m = (int64_t)cb.idx.size();
       for (int64_t q = 0; q < m; ++q) {
         const int64_t lq = loc[cb.idx[q]];
-        const T *src = cb.a.data() + q * m;
+        const T *src = cb.a + q * m;
         for (int64_t p = q; p < m; ++p) {
           const int64_t lp = loc[cb.idx[p]];
           if (lp >= lq) A[lp + lq * f] += src[p];
@@ -808,7 +843,10 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
         }
       }
     }
+    if (first_child < stack.size()) blocks.release(stack[first_child].mark);
     stack.resize(first_child);
+    const double t_b = verbose ? now_s() : 0.0;
+    st.t_assemble += t_b - t_a;
     // pivots
     const int64_t nbw = FrontKernel<T>::nb;
     if ((int64_t)W.size() < f * nbw) W.resize((size_t)(f * nbw));
@@ -817,7 +855,10 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
     fk.A = A; fk.W = W.data(); fk.c1 = c1.data(); fk.c2 = c2.data(); fk.idx = idx.data(); fk.f = f; fk.nF = nF;
     fk.colmax = colmax.data(); fk.prel = perturb_rel;
     fk.pivots = &pivots_done; fk.retry_at = retry_at.data(); fk.tried_at = tried_at.data(); fk.refused = refused.data();
+    if (verbose) fk.t_update = &st.t_update;
     const int64_t npiv = fk.run(ps < 0, u, kind, st);
+    const double t_c = verbose ? now_s() : 0.0;
+    st.t_pivot += t_c - t_b;
     flops += (double)npiv * (double)f * (double)f;
     for (int64_t k = 0; k < npiv; ++k) {
       const int64_t pos = (int64_t)seq.size();
@@ -840,14 +881,19 @@ static int ldlt_factor(int64_t n64, const int64_t *indptr, const int32_t *indice
       cb.parent = ps;
       cb.ndelayed = nF - npiv;
       cb.idx.assign(idx.begin() + npiv, idx.end());
-      cb.a.resize((size_t)(m * m));
+      cb.mark = blocks.mark();
+      cb.a = static_cast<T *>(blocks.take((size_t)(m * m) * sizeof(T)));
       for (int64_t q = 0; q < m; ++q) {
         const T *src = A + (npiv + q) * f + npiv;
-        T *dst = cb.a.data() + q * m;
+        T *dst = cb.a + q * m;
         for (int64_t p = q; p < m; ++p) dst[p] = src[p];
       }
     }
+    if (verbose) st.t_store += now_s() - t_c;
   }
+  if (verbose)
+    fprintf(stderr, "rlh_ldlt_factor:   fronts: assembly %.3f s, pivots + panels %.3f s (of which trailing updates %.3f s), factor columns + contribution blocks %.3f s\n",
+            st.t_assemble, st.t_pivot, st.t_update, st.t_store);
   if ((int64_t)seq.size() != n) { set_error("rlh_ldlt_factor: internal error, %lld of %d pivots", (long long)seq.size(), n); return 1; }
   for (const T &v : lval)
     if (!std::isfinite(re(v))) { set_error("rlh_ldlt_factor: the factorisation broke down (non-finite factor entry)"); return 1; }
