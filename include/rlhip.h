@@ -328,6 +328,21 @@ int rlh_ldlt_destroy(rlh_ldlt_t f);
 int rlh_bdiag_solve(int dtype, int64_t n, const void *d_coef, const int32_t *d_shift, int64_t m,
                     void *X, int64_t ldx);
 
+/* ---- sum of a SMALL host array over the processes of one node (shared memory; host only, no GPU needed)
+ *      The reductions of the hot path end on the host (solver.py:1117-1187 reads the Gram matrices as NumPy arrays):
+ *      on a row-sharded run each rank fetches its partial result and the ranks add them up here -- a flag-per-rank
+ *      hand-off in a POSIX shared-memory segment, the slots summed in rank order (the same bits on every rank) --
+ *      instead of one RCCL launch + copy per reduction.  name: "/..." chosen by rank 0 and told to the others;
+ *      rank 0 creates the segment, the others wait for it; slot_bytes = the largest array ever reduced; after all
+ *      ranks hold a handle rank 0 may remove the name (rlh_shm_unlink: the mappings live on).  dtype: RLH_S or RLH_D
+ *      (complex data as pairs).  All ranks must make the same sequence of calls.  A rank that waits longer than
+ *      RLH_SHM_TIMEOUT seconds (300) for another gets an error. */
+typedef struct rlh_shm *rlh_shm_t;
+int rlh_shm_create(rlh_shm_t *s, const char *name, int rank, int nranks, int64_t slot_bytes);
+int rlh_shm_unlink(const char *name);
+int rlh_shm_allreduce(rlh_shm_t s, int dtype, int64_t count, void *inout);
+int rlh_shm_destroy(rlh_shm_t s);
+
 /* ---- K12: dense operator (dense_numpy.py:153-175; dense_cublas.py:732-776)
  * A: DEVICE, M x N, row-major (order 0, numpy C_CONTIGUOUS, lda >= N) or
  * column-major (order 1, F_CONTIGUOUS, lda >= M).

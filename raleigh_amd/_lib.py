@@ -91,6 +91,10 @@ SIGNATURES = {
     'rlh_ldlt_get_transposed': [_p, _p, _p, _p],
     'rlh_ldlt_destroy': [_p],
     'rlh_bdiag_solve': [_int, _i64, _p, _p, _i64, _p, _i64],
+    'rlh_shm_create': [ctypes.POINTER(_p), ctypes.c_char_p, _int, _int, _i64],
+    'rlh_shm_unlink': [ctypes.c_char_p],
+    'rlh_shm_allreduce': [_p, _int, _i64, _p],
+    'rlh_shm_destroy': [_p],
     'rlh_sptrsv_create': [ctypes.POINTER(_p), _int, _i64, _p, _p, _p, _int, _int],
     'rlh_sptrsv_info': [_p, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     'rlh_sptrsv_solve_chain': [_int, _p, _p, _p, _i64, _p, _i64, _p, _i64],

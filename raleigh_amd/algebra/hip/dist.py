@@ -16,6 +16,8 @@ stays in librlhip.so.  With the "gloo" backend the same code runs on host
 buffers, which is how the CPU test tier covers it (world_size 2).
 """
 
+import ctypes
+
 import numpy as np
 import scipy.sparse as scs
 
@@ -63,6 +65,51 @@ class Comm:
         self._red = None
         self._views = {}
         self.forced_halo_rows = None       # (kept for callers of earlier rounds; the forced one-rank run now cuts the shard in two)
+        self._shm, self._shm_slot = None, 0
+        self._setup_host_reduce()
+
+    def _setup_host_reduce(self):
+        """Small reductions end on the host (the solver reads them as NumPy arrays): with all ranks on ONE node they are
+        summed in a shared-memory segment (rlh_shm_allreduce: every rank fetches its partial, the slots are added in
+        rank order -- the same bits on every rank) instead of one RCCL launch + copy each.  RLH_HOST_REDUCE=0 keeps RCCL
+        for everything; a one-rank run (forced collectives) keeps RCCL unless RLH_HOST_REDUCE=2.  Larger reductions (the
+        N x k blocks of the dense transposed product) and the halo exchange always go through RCCL."""
+        import os
+        import socket
+        import uuid
+        mode = os.environ.get('RLH_HOST_REDUCE', '1')
+        if mode == '0' or (self.size == 1 and mode != '2'):
+            return
+        dist = self.dist
+        hosts = [None] * self.size
+        dist.all_gather_object(hosts, socket.gethostname(), group=self.group)
+        name = ['/rlh_%d_%s' % (os.getpid(), uuid.uuid4().hex[:10])] if self.rank == 0 else [None]
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast_object_list(name, src=src, group=self.group)
+        slot = 1 << 18
+        handle, ok = ctypes.c_void_p(), False
+        if len(set(hosts)) == 1:
+            try:
+                _lib.check(_lib.library().rlh_shm_create(ctypes.byref(handle), name[0].encode(), self.rank, self.size, slot))
+                ok = True
+            except _lib.RlhError:
+                ok = False
+        oks = [None] * self.size
+        dist.all_gather_object(oks, ok, group=self.group)          # (also: every rank holds its mapping from here on)
+        if self.rank == 0 and oks[0]:
+            _lib.library().rlh_shm_unlink(name[0].encode())         # the name goes, the mappings stay: nothing is left in /dev/shm
+        if all(oks):
+            self._shm, self._shm_slot = handle, slot
+        elif ok:
+            _lib.library().rlh_shm_destroy(handle)
+
+    def __del__(self):
+        h, self._shm = getattr(self, '_shm', None), None
+        if h:
+            try:
+                _lib.library().rlh_shm_destroy(h)
+            except Exception:
+                pass
 
     def buffer(self, nbytes):
         """A communication buffer (device memory under RCCL, host memory under gloo)."""
@@ -78,6 +125,16 @@ class Comm:
         """Sums `count` elements of dtype np_dtype held in `buf` over the ranks and
         returns them as a host array."""
         np_dtype = np.dtype(np_dtype)
+        if self._shm is not None and count * np_dtype.itemsize <= self._shm_slot and (self.size > 1 or self.force):
+            out = np.empty((count,), dtype=np_dtype)
+            if self.on_device:      # this rank's partial: pinned staging + one stream synchronisation inside the library
+                _lib.check(_lib.lib().rlh_fetch(_lib.host_ptr(out), buf.data_ptr(), out.nbytes))
+            else:
+                out.view(np.uint8)[:] = buf[:out.nbytes].numpy()
+            real = np.dtype(_REAL[np_dtype.type])
+            _lib.check(_lib.library().rlh_shm_allreduce(self._shm, _lib.DTYPE_CODE[real.type], out.nbytes // real.itemsize,
+                                                        _lib.host_ptr(out)))
+            return out
         key = (buf.data_ptr(), np_dtype.str, count)
         view = self._views.get(key)
         if view is None:

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(PKG, 'lib')
 LIBPATH = os.path.join(LIBDIR, 'librlhip.so')
 SOURCES = ['context', 'gram', 'update', 'spmm', 'spmm_wide_build', 'spmm_wide_s', 'spmm_wide_d', 'spmm_wide_c',
            'spmm_wide_z', 'sptrsv', 'dense']
-HOST_SOURCES = ['ldlt_host']        # plain C++ (host only): compiled by the same driver, no offload
+HOST_SOURCES = ['ldlt_host', 'shm_reduce']        # plain C++ (host only): compiled by the same driver, no offload
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
 
@@ -73,7 +73,7 @@ def build_library(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES) + len(HOST_SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES + HOST_SOURCES))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs + ['-lrt']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])

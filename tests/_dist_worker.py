@@ -26,6 +26,26 @@ def main():
     off = partition(1000, size)
     assert off[0] == 0 and off[-1] == 1000 and np.all(np.diff(off) >= 0)
 
+    # small reductions go through the shared-memory segment of the node (all ranks of this test share one): the same
+    # numbers as the backend's all-reduce, the same BITS on every rank, and a reduction too large for a slot still works
+    import torch
+    assert comm._shm is not None and os.environ.get('RLH_HOST_REDUCE', '1') != '0'
+    rng = np.random.default_rng(100 + rank)
+    for dtp, count in ((np.float64, 1), (np.float64, 1024), (np.complex128, 64 * 64), (np.float32, 300), (np.float64, 70000)):
+        part = rng.standard_normal(count).astype(dtp)
+        if np.dtype(dtp).kind == 'c':
+            part = part + 1j * rng.standard_normal(count)
+        buf = comm.reduction_buffer(part.nbytes)
+        buf[:part.nbytes] = torch.from_numpy(part.view(np.uint8).copy())
+        got = comm.allreduce_from_device(buf, dtp, count)
+        ref = torch.from_numpy(part.view(np.float64 if np.dtype(dtp).itemsize % 8 == 0 else np.float32).copy())
+        dist.all_reduce(ref)
+        want = ref.numpy().view(dtp)
+        assert np.allclose(got, want, rtol=1e-5 if dtp == np.float32 else 1e-13, atol=0)
+        everyone = [None] * size
+        dist.all_gather_object(everyone, got.tobytes())
+        assert all(b == everyone[0] for b in everyone)
+
     for key, dt in (('d', np.float64), ('z', np.complex128), ('s', np.float32)):
         rng = np.random.default_rng(3)         # same global data on every rank
         n, m, k = 1003, 6, 4

@@ -375,6 +375,24 @@ class FakeLib:
     def rlh_factors_destroy(self, *a):
         return self._real().rlh_factors_destroy(*a)
 
+    def rlh_shm_create(self, *a):
+        rc = self._real().rlh_shm_create(*a)
+        if rc:
+            self._err = self._real().rlh_last_error()
+        return rc
+
+    def rlh_shm_unlink(self, *a):
+        return self._real().rlh_shm_unlink(*a)
+
+    def rlh_shm_allreduce(self, *a):
+        rc = self._real().rlh_shm_allreduce(*a)
+        if rc:
+            self._err = self._real().rlh_last_error()
+        return rc
+
+    def rlh_shm_destroy(self, *a):
+        return self._real().rlh_shm_destroy(*a)
+
     def rlh_ldlt_factor(self, *a):
         rc = self._real().rlh_ldlt_factor(*a)
         if rc:
