@@ -63,6 +63,38 @@ def test_reductions_through_rccl(comm, dt):
     assert np.array_equal(X.data(), x)                    # all-gather of the shards
 
 
+@pytest.mark.parametrize('dt', [np.float64, np.complex128, np.float32])
+def test_reductions_through_shared_memory(comm, monkeypatch, dt):
+    """The same reductions with the small results summed in the node's shared-memory segment (what a multi-rank run on one
+    node does by default; asked for at one rank by RLH_HOST_REDUCE=2): the partial comes off the device through the
+    library's fetch, the sum happens on the host -- no collective is launched for it."""
+    from raleigh_amd.algebra.hip.dist import Comm, ShardedVectors
+    monkeypatch.setenv('RLH_HOST_REDUCE', '2')
+    c2 = Comm(force_collectives=True)
+    assert c2._shm is not None
+    calls = []
+    real = c2.dist.all_reduce
+    monkeypatch.setattr(c2.dist, 'all_reduce', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    rng = np.random.default_rng(6)
+    n, m, k = 50021, 12, 7
+    x = rng.standard_normal((m, n)).astype(dt)
+    y = rng.standard_normal((k, n)).astype(dt)
+    if dt == np.complex128:
+        x = x + 1j * rng.standard_normal((m, n))
+        y = y - 1j * rng.standard_normal((k, n))
+    tol = 2e-5 if dt == np.float32 else 1e-13
+    X, Y = ShardedVectors(x, comm=c2), ShardedVectors(y, comm=c2)
+    assert rel(X.dot(Y), ops.gram(x, y)) < tol
+    assert rel(X.dots(X), ops.dots(x, x)) < tol
+    rb = X.reduction_batch()
+    rb.gram([X], [Y, X])
+    rb.dots(Y, Y)
+    g, d = rb.run()
+    assert rel(g[:k], ops.gram(x, y)) < tol and rel(g[k:], ops.gram(x, x)) < tol and rel(d, ops.dots(y, y)) < tol
+    assert not calls
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('rlh_')]
+
+
 @pytest.mark.parametrize('dt', [np.float64, np.float32])
 def test_halo_exchange_with_itself(comm, dt):
     """The forced one-rank run cuts the shard into two virtual ranks (RLH_FORCE_COLLECTIVES semantics of
