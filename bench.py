@@ -930,7 +930,9 @@ def main():
         out['collectives'] = {'backend': 'gloo (rehearsal)' if rehearsal else 'nccl (RCCL)', 'forced_at_one_rank': bool(args.force_dist),
                               'round_trips_per_step': {'headline': 13, 'fused': 5},
                               'round_trip_us': round(max_over_ranks(float(np.median(trips))) * 1e6, 1),
-                              'what': 'median wall time of one all-reduce(m x m fp64) + result fetch, max over ranks'}
+                              'small_reductions': ('shared memory of the node (rlh_shm_allreduce: partial fetched, slots summed in rank order)'
+                                                   if getattr(comm, '_shm', None) is not None else 'the backend all-reduce on the stream'),
+                              'what': 'median wall time of one reduction of an m x m fp64 block over the ranks + the result on the host, max over ranks'}
 
     def guarded(key, fn):
         """A failure on ANY rank is agreed on by all of them (the others would otherwise wait in the next
