@@ -121,20 +121,28 @@ class Comm:
             self._views.clear()
         return self._red
 
+    def sums_on_host(self, nbytes):
+        """Whether a reduction of `nbytes` goes through the node's shared-memory segment (the same answer on every rank)."""
+        return self._shm is not None and nbytes <= self._shm_slot and (self.size > 1 or self.force)
+
+    def sum_on_host(self, out):
+        """out (this rank's partial, a host array) <- the sum over the ranks, in rank order; returns out."""
+        real = np.dtype(_REAL[out.dtype.type])
+        _lib.check(_lib.library().rlh_shm_allreduce(self._shm, _lib.DTYPE_CODE[real.type], out.nbytes // real.itemsize,
+                                                    _lib.host_ptr(out)))
+        return out
+
     def allreduce_from_device(self, buf, np_dtype, count):
         """Sums `count` elements of dtype np_dtype held in `buf` over the ranks and
         returns them as a host array."""
         np_dtype = np.dtype(np_dtype)
-        if self._shm is not None and count * np_dtype.itemsize <= self._shm_slot and (self.size > 1 or self.force):
+        if self.sums_on_host(count * np_dtype.itemsize):
             out = np.empty((count,), dtype=np_dtype)
             if self.on_device:      # this rank's partial: pinned staging + one stream synchronisation inside the library
                 _lib.check(_lib.lib().rlh_fetch(_lib.host_ptr(out), buf.data_ptr(), out.nbytes))
             else:
                 out.view(np.uint8)[:] = buf[:out.nbytes].numpy()
-            real = np.dtype(_REAL[np_dtype.type])
-            _lib.check(_lib.library().rlh_shm_allreduce(self._shm, _lib.DTYPE_CODE[real.type], out.nbytes // real.itemsize,
-                                                        _lib.host_ptr(out)))
-            return out
+            return self.sum_on_host(out)
         key = (buf.data_ptr(), np_dtype.str, count)
         view = self._views.get(key)
         if view is None:
