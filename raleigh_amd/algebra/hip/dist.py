@@ -92,7 +92,7 @@ class Comm:
             try:
                 _lib.check(_lib.library().rlh_shm_create(ctypes.byref(handle), name[0].encode(), self.rank, self.size, slot))
                 ok = True
-            except _lib.RlhError:
+            except Exception:                                   # (whatever it was: the ranks decide together below)
                 ok = False
         oks = [None] * self.size
         dist.all_gather_object(oks, ok, group=self.group)          # (also: every rank holds its mapping from here on)
