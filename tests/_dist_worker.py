@@ -29,7 +29,7 @@ def main():
     # small reductions go through the shared-memory segment of the node (all ranks of this test share one): the same
     # numbers as the backend's all-reduce, the same BITS on every rank, and a reduction too large for a slot still works
     import torch
-    assert comm._shm is not None and os.environ.get('RLH_HOST_REDUCE', '1') != '0'
+    assert (comm._shm is not None) == (os.environ.get('RLH_HOST_REDUCE', '1') != '0')
     rng = np.random.default_rng(100 + rank)
     for dtp, count in ((np.float64, 1), (np.float64, 1024), (np.complex128, 64 * 64), (np.float32, 300), (np.float64, 70000)):
         part = rng.standard_normal(count).astype(dtp)
